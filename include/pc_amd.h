@@ -1,0 +1,144 @@
+/*
+ * pc_amd.h - C ABI of the MI355X (gfx950) neighbourhood stage.
+ *
+ * The reference has no FFI of its own: its hot path is eight method calls on
+ * open3d.geometry.PointCloud objects made from Python (reference files cited per entry
+ * point below).  This header is what a binding for that path binds instead of the Open3D
+ * wheel: plain pointers and sizes, no C++ or torch types.
+ *
+ * Conventions
+ *  - Every pointer named *_dev is DEVICE memory owned by the caller; every other pointer is
+ *    host memory.  Point arrays are N x 3 row-major.  dtype is PC_F32 or PC_F64.
+ *  - Every function returns 0 on success or a negative pc_status; pc_last_error() gives the
+ *    message.  Nothing throws or aborts across the boundary.
+ *  - Every function selects its context's device itself (the HIP current device is
+ *    thread-local and the app calls from worker QThreads, reference
+ *    app/Controllers/app_controller.py:428-441, 528-543), enqueues on `stream`
+ *    (a hipStream_t passed as void*, NULL = default stream) and, where it returns host
+ *    values, synchronises that stream before returning.
+ *  - A context may be used by one thread at a time; use one context per thread.
+ *  - Neighbour order everywhere: ascending squared distance computed in fp64 as
+ *    ((dx*dx)+dy*dy)+dz*dz with dx = q - p; exact ties -> lower point index first.
+ */
+#ifndef PC_AMD_H
+#define PC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pc_ctx pc_ctx;
+typedef struct pc_grid pc_grid;
+
+enum pc_dtype { PC_F32 = 0, PC_F64 = 1 };
+
+enum pc_status {
+    PC_OK = 0,
+    PC_BAD_ARG = -1,   /* illegal parameter (Open3D raises RuntimeError for the same input) */
+    PC_NOMEM = -2,     /* device or host allocation failed */
+    PC_HIP_ERROR = -3, /* a HIP runtime call failed */
+    PC_OVERFLOW = -4,  /* voxel_size too small for the cloud's extent */
+    PC_NO_DEVICE = -5
+};
+
+/* Largest k accepted by the neighbour searches. */
+#define PC_MAX_K 64
+
+/* ---- context ---------------------------------------------------------------------------- */
+int pc_create(int device, pc_ctx **out);
+void pc_destroy(pc_ctx *ctx);
+const char *pc_last_error(const pc_ctx *ctx);
+const char *pc_status_string(int status);
+int pc_abi_version(void);
+
+/* ---- bounding box / rigid edits ------------------------------------------------------------
+ * Replaces PointCloud.get_axis_aligned_bounding_box / translate / scale as used by
+ * reference app/Core/pointcloud_preprocess.py:45-53 and :104-105. */
+int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_min[3], double out_max[3],
+            void *stream);
+/* In place on an fp64 cloud: if t != NULL p += t; then if has_scale p = (p - c) * s + c. */
+int pc_affine(pc_ctx *ctx, double *xyz_dev, int64_t n, const double *t, int has_scale, double s, const double *c,
+              void *stream);
+
+/* ---- voxel down-sampling -------------------------------------------------------------------
+ * Replaces PointCloud.voxel_down_sample (reference app/Core/pointcloud_preprocess.py:96,
+ * app/Infrastructure/filtering_adapter.py:88): voxel index = floor((p - (min - vs/2)) / vs)
+ * in fp64, output = per-voxel mean of points / normals / colors, summed in point-index
+ * order.  Output order: ascending (iz, iy, ix).  Output buffers hold n rows; *out_m receives
+ * the number of voxels.  normals / colors / out_count / out_ijk may be NULL. */
+int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
+                        const double *colors_dev, int64_t n, double voxel_size, double *out_xyz_dev,
+                        double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
+                        int32_t *out_ijk_dev, int64_t *out_m, void *stream);
+/* Voxel index triple of every input point (n x 3 int32) and the voxel grid dimensions. */
+int pc_voxel_assign(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double voxel_size,
+                    int32_t *out_ijk_dev, int32_t out_dims[3], void *stream);
+
+/* ---- spatial index -------------------------------------------------------------------------
+ * Replaces the KD-tree Open3D builds inside estimate_normals / remove_statistical_outlier /
+ * remove_radius_outlier / compute_nearest_neighbor_distance (KDTreeFlann::SetGeometry):
+ * a uniform grid over the bounding box, points radix-sorted by cell (x fastest), with a
+ * cell-start table.  cell_size <= 0 chooses the edge from the point count and k_hint. */
+int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double cell_size, int k_hint,
+                  pc_grid **out, void *stream);
+void pc_grid_destroy(pc_ctx *ctx, pc_grid *grid);
+/* info[0..2] = dims, info[3] = cell edge, info[4] = n, info[5] = device bytes held. */
+int pc_grid_info(const pc_grid *grid, double info[6]);
+/* Sorted-position -> original-index map of the grid (n x int32, device memory owned by the
+ * grid).  Sorted position s is the unit the *_range entry points shard over. */
+const int32_t *pc_grid_perm_dev(const pc_grid *grid);
+
+/* ---- exact kNN -----------------------------------------------------------------------------
+ * Replaces KDTreeFlann::SearchKNN / SearchHybrid as reached from the calls listed above.
+ * queries_dev == NULL: every point of the grid queries itself (the point is its own first
+ * neighbour); results are written at the point's ORIGINAL index.  radius < 0: plain kNN;
+ * radius >= 0: hybrid search (only neighbours with d2 < radius^2).  Rows are padded with
+ * idx = -1, d2 = +inf.  out_d2_dev has element type d2_dtype.  Any out_* may be NULL. */
+int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype, int64_t nq, int k, double radius,
+           int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, void *stream);
+/* Self-query restricted to sorted positions [s_begin, s_end) (multi-GPU query sharding). */
+int pc_knn_range(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
+                 int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, void *stream);
+
+/* ---- consumers fused onto the kNN result -------------------------------------------------------
+ * pc_sor_avg: per-point mean neighbour distance of PointCloud.remove_statistical_outlier
+ * (reference app/Infrastructure/filtering_adapter.py:91): kNN with k = nb_neighbors
+ * including the point itself, avg = sum(sqrt(d2)) / found, written at the original index. */
+int pc_sor_avg(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double *out_avg_dev,
+               void *stream);
+/* Deterministic partial sums over avg[0..n): *sum_pos = sum of avg > 0, *n_valid = #(avg >= 0). */
+int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, int64_t *n_valid, void *stream);
+/* *sq = sum over avg > 0 of (avg - mean)^2. */
+int pc_sor_sqsum(pc_ctx *ctx, const double *avg_dev, int64_t n, double mean, double *sq, void *stream);
+/* mask[i] = avg > 0 && avg < threshold; kept indices ascending; *n_kept = their number.
+ * out_mask_dev / out_kept_dev may be NULL. */
+int pc_sor_select(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshold, uint8_t *out_mask_dev,
+                  int32_t *out_kept_dev, int64_t *n_kept, void *stream);
+
+/* PCA normals of PointCloud.estimate_normals(fast_normal_computation=True)
+ * (reference app/Core/pointcloud_preprocess.py:109-114): neighbours = kNN (radius < 0) or
+ * hybrid search; fewer than 3 -> (0,0,1); else one-pass covariance and the closed-form
+ * symmetric 3x3 eigen-solver; prior_dev (n x 3, may be NULL) flips the sign to agree. */
+int pc_normals(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
+               const double *prior_dev, double *out_normals_dev, void *stream);
+
+/* Neighbour count of PointCloud.remove_radius_outlier (filtering_adapter.py:94):
+ * points with d2 < radius^2 (strict, self included).  queries_dev == NULL: self-query over
+ * sorted positions [s_begin, s_end), written at the original index. */
+int pc_radius_count(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype, int64_t nq,
+                    int64_t s_begin, int64_t s_end, double radius, int32_t *out_cnt_dev, void *stream);
+
+/* PointCloud.compute_nearest_neighbor_distance (filtering_adapter.py:49,
+ * app/Core/mesh_reconstruction.py:112): sqrt of the second-smallest d2, 0 if none. */
+int pc_nn_distance(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, double *out_dev, void *stream);
+
+/* Row gather dst[i] = src[idx[i]] for m rows of 3 doubles (PointCloud.select_by_index). */
+int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
+                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PC_AMD_H */

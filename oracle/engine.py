@@ -1,0 +1,48 @@
+"""Checker engine: runs the PointCloud method surface on the CPU oracle.  TESTS ONLY.
+
+Lets the host logic (app/Core, app/Infrastructure mirrors) be exercised without a GPU and
+gives GPU tests an end-to-end expected result.  Never imported by the product package.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import pc_oracle as O
+
+
+class OracleEngine:
+    name = "oracle"
+
+    def bbox(self, pts, cache):
+        return O.bbox(pts)
+
+    def affine(self, pts, cache, t, s, c):
+        out = np.array(pts, dtype=np.float64, copy=True)
+        if t is not None:
+            out += np.asarray(t, dtype=np.float64)
+        if s is not None:
+            c = np.asarray(c, dtype=np.float64)
+            out = (out - c) * s + c
+        return np.ascontiguousarray(out)
+
+    def voxel_downsample(self, pts, nrm, col, vs, cache):
+        return O.voxel_downsample(pts, vs, nrm, col)
+
+    def normals(self, pts, k, radius, prior, cache):
+        return O.normals(pts, k, radius, prior)
+
+    def sor(self, pts, k, std_ratio, cache):
+        key = ("sor_avg", k)
+        if key not in cache:
+            cache[key] = O.sor_avg(pts, k)
+        mask, _ = O.sor_threshold(cache[key], std_ratio)
+        return np.nonzero(mask)[0]
+
+    def radius_count(self, pts, radius, cache):
+        return O.radius_count(pts, radius)
+
+    def nn_distance(self, pts, cache):
+        return O.nn_distance(pts)
+
+    def knn(self, pts, q, k, radius, cache):
+        return O.knn(pts, q, k, None if radius < 0 else radius)

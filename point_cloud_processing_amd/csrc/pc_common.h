@@ -1,0 +1,94 @@
+// Shared host-side declarations of the gfx950 neighbourhood-stage library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "pc_amd.h"
+
+#define PC_WAVE 64  // gfx950 wavefront width (hard-coded: not a host compile-time constant)
+
+struct pc_ctx {
+    int device = 0;
+    std::string err;
+    // grow-only cache of device blocks so that per-frame calls do not hipMalloc
+    struct Block {
+        void *p;
+        size_t bytes;
+        bool used;
+    };
+    std::vector<Block> pool;
+    size_t pool_bytes = 0;
+
+    void *alloc(size_t bytes);
+    void release(void *p);
+    void trim();
+};
+
+int pc_fail(pc_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+
+#define PC_HIP(call)                                                            \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return pc_fail(ctx, PC_HIP_ERROR, #call, e__);   \
+    } while (0)
+
+#define PC_TRY(call)               \
+    do {                           \
+        int rc__ = (call);         \
+        if (rc__ != PC_OK) return rc__; \
+    } while (0)
+
+// RAII handle on a pooled device block
+struct Scratch {
+    pc_ctx *ctx;
+    void *p = nullptr;
+    Scratch(pc_ctx *c, size_t bytes) : ctx(c) { p = c->alloc(bytes ? bytes : 16); }
+    ~Scratch() {
+        if (p) ctx->release(p);
+    }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    template <typename T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+    bool ok() const { return p != nullptr; }
+};
+
+// Points sorted by cell, one record per point: coordinates + original index.
+struct __attribute__((aligned(16))) Rec32 {
+    float x, y, z;
+    int32_t idx;
+};
+struct __attribute__((aligned(32))) Rec64 {
+    double x, y, z;
+    int64_t idx;
+};
+
+struct GridParams {
+    double o[3];   // origin (grid min, or voxel min bound)
+    double s;      // kNN grid: 1/cell ; voxel grid: voxel size
+    double cell;   // cell edge
+    int32_t dim[3];
+};
+
+struct pc_grid {
+    int64_t n = 0;
+    int dtype = PC_F32;
+    GridParams gp{};
+    void *rec = nullptr;          // Rec32[n] or Rec64[n]
+    uint32_t *cell_start = nullptr;  // ncell + 1
+    int32_t *perm = nullptr;      // sorted position -> original index
+    int64_t ncell = 0;
+    size_t bytes = 0;
+};
+
+// pc_sort.hip
+int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
+                        int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp);
+int pc_exclusive_scan_u32(pc_ctx *ctx, uint32_t *data, int64_t n, hipStream_t st);
+// flags (0/1 bytes) -> ascending indices of the set flags; *count on host (synchronises)
+int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_idx, int64_t *count, hipStream_t st);

@@ -1,0 +1,577 @@
+// Context, bounding box, rigid edits, voxel down-sampling and the uniform-grid spatial index.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "pc_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+int pc_fail(pc_ctx *ctx, int status, const char *what, hipError_t e) {
+    if (ctx) {
+        ctx->err = std::string(pc_status_string(status)) + ": " + what;
+        if (e != hipSuccess) ctx->err += std::string(" (") + hipGetErrorString(e) + ")";
+    }
+    return status;
+}
+
+void *pc_ctx::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    int best = -1;
+    for (size_t i = 0; i < pool.size(); i++)
+        if (!pool[i].used && pool[i].bytes >= bytes && pool[i].bytes <= 2 * bytes + (1u << 20))
+            if (best < 0 || pool[i].bytes < pool[best].bytes) best = (int)i;
+    if (best >= 0) {
+        pool[best].used = true;
+        return pool[best].p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        trim();  // drop cached free blocks and retry once
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    pool.push_back({p, bytes, true});
+    pool_bytes += bytes;
+    return p;
+}
+
+void pc_ctx::release(void *p) {
+    for (auto &b : pool)
+        if (b.p == p) {
+            b.used = false;
+            return;
+        }
+}
+
+void pc_ctx::trim() {
+    std::vector<Block> keep;
+    for (auto &b : pool) {
+        if (b.used)
+            keep.push_back(b);
+        else {
+            (void)hipFree(b.p);
+            pool_bytes -= b.bytes;
+        }
+    }
+    pool.swap(keep);
+}
+
+extern "C" {
+
+int pc_abi_version(void) { return 1; }
+
+const char *pc_status_string(int status) {
+    switch (status) {
+        case PC_OK: return "ok";
+        case PC_BAD_ARG: return "bad argument";
+        case PC_NOMEM: return "out of memory";
+        case PC_HIP_ERROR: return "HIP error";
+        case PC_OVERFLOW: return "voxel_size is too small";
+        case PC_NO_DEVICE: return "no such device";
+        default: return "unknown status";
+    }
+}
+
+int pc_create(int device, pc_ctx **out) {
+    if (!out) return PC_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PC_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PC_NO_DEVICE;
+    pc_ctx *c = new (std::nothrow) pc_ctx();
+    if (!c) return PC_NOMEM;
+    c->device = device;
+    *out = c;
+    return PC_OK;
+}
+
+void pc_destroy(pc_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &b : ctx->pool) (void)hipFree(b.p);
+    delete ctx;
+}
+
+const char *pc_last_error(const pc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bbox(const T *__restrict__ xyz, int64_t n, double *__restrict__ partial) {
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            double v = (double)xyz[3 * i + a];
+            mn[a] = fmin(mn[a], v);
+            mx[a] = fmax(mx[a], v);
+        }
+    }
+    __shared__ double red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fmin(mn[a], __shfl_down(mn[a], o, 64));
+            mx[a] = fmax(mx[a], __shfl_down(mx[a], o, 64));
+        }
+        if (lane == 0) {
+            red[wave][a] = mn[a];
+            red[wave][3 + a] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = red[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
+        partial[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_bbox_final(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+    int a = threadIdx.x;
+    if (a >= 6) return;
+    double v = partial[a];
+    for (int b = 1; b < nb; b++) v = a < 3 ? fmin(v, partial[(size_t)b * 6 + a]) : fmax(v, partial[(size_t)b * 6 + a]);
+    out[a] = v;
+}
+
+struct Affine {
+    double t[3], c[3], s;
+    int has_t, has_s;
+};
+
+__global__ __launch_bounds__(256) void k_affine(double *__restrict__ xyz, int64_t n3, Affine af) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    int a = (int)(i % 3);
+    double v = xyz[i];
+    if (af.has_t) v += af.t[a];
+    if (af.has_s) v = (v - af.c[a]) * af.s + af.c[a];
+    xyz[i] = v;
+}
+
+// voxel grid: index = floor((p - o) / s), true fp64 divide (Open3D VoxelDownSample order)
+// kNN grid:   index = clamp(floor((p - o) * s)), bucketing only
+template <typename T, bool VOXEL>
+__global__ __launch_bounds__(256) void k_cell_keys(const T *__restrict__ xyz, int64_t n, GridParams gp,
+                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                    int32_t *__restrict__ ijk_out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double v = (double)xyz[3 * i + a];
+        if (VOXEL) {
+            c[a] = (int32_t)floor((v - gp.o[a]) / gp.s);
+        } else {
+            double t = floor((v - gp.o[a]) * gp.s);
+            c[a] = !(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int32_t)t);
+        }
+    }
+    if (keys) {
+        keys[i] = ((uint64_t)c[2] * (uint64_t)gp.dim[1] + (uint64_t)c[1]) * (uint64_t)gp.dim[0] + (uint64_t)c[0];
+        vals[i] = (uint32_t)i;
+    }
+    if (ijk_out) {
+        ijk_out[3 * i] = c[0];
+        ijk_out[3 * i + 1] = c[1];
+        ijk_out[3 * i + 2] = c[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cell_count(const uint64_t *__restrict__ keys, int64_t n,
+                                                     uint32_t *__restrict__ cnt) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[keys[i]], 1u);
+}
+
+template <typename T, typename REC>
+__global__ __launch_bounds__(256) void k_gather_records(const T *__restrict__ xyz, const uint32_t *__restrict__ vals,
+                                                         int64_t n, REC *__restrict__ rec,
+                                                         int32_t *__restrict__ perm) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t j = vals[i];
+    REC r;
+    r.x = xyz[3 * (size_t)j];
+    r.y = xyz[3 * (size_t)j + 1];
+    r.z = xyz[3 * (size_t)j + 2];
+    r.idx = (decltype(r.idx))j;
+    rec[i] = r;
+    perm[i] = (int32_t)j;
+}
+
+__global__ __launch_bounds__(256) void k_segment_heads(const uint64_t *__restrict__ keys, int64_t n,
+                                                        uint8_t *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// one thread per voxel, sequential sums in point-index order (the sort is stable)
+template <typename T>
+__global__ __launch_bounds__(256) void k_voxel_reduce(const T *__restrict__ xyz, const double *__restrict__ nrm,
+                                                       const double *__restrict__ col,
+                                                       const uint64_t *__restrict__ keys,
+                                                       const uint32_t *__restrict__ vals,
+                                                       const int32_t *__restrict__ heads, int64_t m, int64_t n,
+                                                       GridParams gp, double *__restrict__ out_xyz,
+                                                       double *__restrict__ out_nrm, double *__restrict__ out_col,
+                                                       int32_t *__restrict__ out_cnt, int32_t *__restrict__ out_ijk) {
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= m) return;
+    int64_t s = heads[v], e = v + 1 < m ? heads[v + 1] : n;
+    double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+    for (int64_t t = s; t < e; t++) {
+        size_t i = vals[t];
+#pragma unroll
+        for (int a = 0; a < 3; a++) sp[a] += (double)xyz[3 * i + a];
+        if (nrm) {
+            double n0 = nrm[3 * i], n1 = nrm[3 * i + 1], n2 = nrm[3 * i + 2];
+            if (!isnan(n0) && !isnan(n1) && !isnan(n2)) {
+                sn[0] += n0;
+                sn[1] += n1;
+                sn[2] += n2;
+            }
+        }
+        if (col) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) sc[a] += col[3 * i + a];
+        }
+    }
+    double cnt = (double)(e - s);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        out_xyz[3 * v + a] = sp[a] / cnt;
+        if (nrm && out_nrm) out_nrm[3 * v + a] = sn[a] / cnt;
+        if (col && out_col) out_col[3 * v + a] = sc[a] / cnt;
+    }
+    if (out_cnt) out_cnt[v] = (int32_t)(e - s);
+    if (out_ijk) {
+        uint64_t key = keys[s];
+        out_ijk[3 * v] = (int32_t)(key % (uint64_t)gp.dim[0]);
+        out_ijk[3 * v + 1] = (int32_t)((key / (uint64_t)gp.dim[0]) % (uint64_t)gp.dim[1]);
+        out_ijk[3 * v + 2] = (int32_t)(key / ((uint64_t)gp.dim[0] * (uint64_t)gp.dim[1]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const double *__restrict__ src, const int32_t *__restrict__ idx,
+                                                      int64_t m3, double *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m3) return;
+    dst[i] = src[3 * (size_t)idx[i / 3] + (i % 3)];
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+int bits_for(uint64_t v) {
+    int b = 0;
+    while (v) {
+        b++;
+        v >>= 1;
+    }
+    return b > 0 ? b : 1;
+}
+
+int bbox_impl(pc_ctx *ctx, const void *xyz, int dtype, int64_t n, double mn[3], double mx[3], hipStream_t st) {
+    if (n <= 0) {
+        for (int a = 0; a < 3; a++) mn[a] = mx[a] = 0.0;
+        return PC_OK;
+    }
+    int nb = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    Scratch part(ctx, sizeof(double) * 6 * (size_t)(nb + 1));
+    if (!part.ok()) return pc_fail(ctx, PC_NOMEM, "bbox scratch");
+    double *p = part.as<double>();
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_bbox<float>, dim3(nb), dim3(256), 0, st, (const float *)xyz, n, p);
+    else
+        hipLaunchKernelGGL(k_bbox<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz, n, p);
+    hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, st, p, nb, p + (size_t)nb * 6);
+    PC_HIP(hipGetLastError());
+    double h[6];
+    PC_HIP(hipMemcpyAsync(h, p + (size_t)nb * 6, sizeof(h), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    for (int a = 0; a < 3; a++) {
+        mn[a] = h[a];
+        mx[a] = h[3 + a];
+    }
+    return PC_OK;
+}
+
+// voxel grid parameters exactly as Open3D derives them
+int voxel_params(pc_ctx *ctx, const double mn[3], const double mx[3], double vs, GridParams *gp) {
+    double ext = -INFINITY;
+    for (int a = 0; a < 3; a++) {
+        gp->o[a] = mn[a] - vs * 0.5;
+        double vmax = mx[a] + vs * 0.5;
+        ext = std::max(ext, vmax - gp->o[a]);
+    }
+    if (vs * (double)INT32_MAX < ext) return pc_fail(ctx, PC_OVERFLOW, "voxel_size is too small.");
+    gp->s = vs;
+    gp->cell = vs;
+    for (int a = 0; a < 3; a++) gp->dim[a] = (int32_t)floor((mx[a] - gp->o[a]) / vs) + 1;
+    // linear key must fit 63 bits
+    long double tot = (long double)gp->dim[0] * (long double)gp->dim[1] * (long double)gp->dim[2];
+    if (tot >= 9.0e18L) return pc_fail(ctx, PC_OVERFLOW, "voxel grid has more than 2^63 cells");
+    return PC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_min[3], double out_max[3],
+            void *stream) {
+    if (!ctx || !out_min || !out_max || n < 0 || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_bbox");
+    PC_HIP(hipSetDevice(ctx->device));
+    return bbox_impl(ctx, xyz_dev, dtype, n, out_min, out_max, (hipStream_t)stream);
+}
+
+int pc_affine(pc_ctx *ctx, double *xyz_dev, int64_t n, const double *t, int has_scale, double s, const double *c,
+              void *stream) {
+    if (!ctx || n < 0 || (n > 0 && !xyz_dev) || (has_scale && !c)) return pc_fail(ctx, PC_BAD_ARG, "pc_affine");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return PC_OK;
+    Affine af{};
+    af.has_t = t != nullptr;
+    af.has_s = has_scale != 0;
+    af.s = s;
+    for (int a = 0; a < 3; a++) {
+        af.t[a] = t ? t[a] : 0.0;
+        af.c[a] = c ? c[a] : 0.0;
+    }
+    hipLaunchKernelGGL(k_affine, dim3(blocks_for(3 * n, 256)), dim3(256), 0, (hipStream_t)stream, xyz_dev, 3 * n, af);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_voxel_assign(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double voxel_size, int32_t *out_ijk_dev,
+                    int32_t out_dims[3], void *stream) {
+    if (!ctx || n < 0 || (n > 0 && (!xyz_dev || !out_ijk_dev)) || (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_assign");
+    if (!(voxel_size > 0.0)) return pc_fail(ctx, PC_BAD_ARG, "voxel_size <= 0.");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (out_dims) out_dims[0] = out_dims[1] = out_dims[2] = 0;
+        return PC_OK;
+    }
+    double mn[3], mx[3];
+    PC_TRY(bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st));
+    GridParams gp{};
+    PC_TRY(voxel_params(ctx, mn, mx, voxel_size, &gp));
+    if (out_dims)
+        for (int a = 0; a < 3; a++) out_dims[a] = gp.dim[a];
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL((k_cell_keys<float, true>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                           (const float *)xyz_dev, n, gp, (uint64_t *)nullptr, (uint32_t *)nullptr, out_ijk_dev);
+    else
+        hipLaunchKernelGGL((k_cell_keys<double, true>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                           (const double *)xyz_dev, n, gp, (uint64_t *)nullptr, (uint32_t *)nullptr, out_ijk_dev);
+    PC_HIP(hipGetLastError());
+    PC_HIP(hipStreamSynchronize(st));
+    return PC_OK;
+}
+
+int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
+                        const double *colors_dev, int64_t n, double voxel_size, double *out_xyz_dev,
+                        double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
+                        int32_t *out_ijk_dev, int64_t *out_m, void *stream) {
+    if (!ctx || !out_m || n < 0 || n >= INT32_MAX || (n > 0 && (!xyz_dev || !out_xyz_dev)) ||
+        (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_downsample");
+    if (!(voxel_size > 0.0)) return pc_fail(ctx, PC_BAD_ARG, "voxel_size <= 0.");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *out_m = 0;
+    if (n == 0) return PC_OK;
+    double mn[3], mx[3];
+    PC_TRY(bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st));
+    GridParams gp{};
+    PC_TRY(voxel_params(ctx, mn, mx, voxel_size, &gp));
+
+    Scratch keys(ctx, sizeof(uint64_t) * (size_t)n), keys2(ctx, sizeof(uint64_t) * (size_t)n);
+    Scratch vals(ctx, sizeof(uint32_t) * (size_t)n), vals2(ctx, sizeof(uint32_t) * (size_t)n);
+    Scratch flags(ctx, (size_t)n), heads(ctx, sizeof(int32_t) * (size_t)n);
+    if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok() || !flags.ok() || !heads.ok())
+        return pc_fail(ctx, PC_NOMEM, "voxel scratch");
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL((k_cell_keys<float, true>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                           (const float *)xyz_dev, n, gp, keys.as<uint64_t>(), vals.as<uint32_t>(), (int32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((k_cell_keys<double, true>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                           (const double *)xyz_dev, n, gp, keys.as<uint64_t>(), vals.as<uint32_t>(), (int32_t *)nullptr);
+    uint64_t ncell = (uint64_t)gp.dim[0] * (uint64_t)gp.dim[1] * (uint64_t)gp.dim[2];
+    bool in_tmp = false;
+    PC_TRY(pc_radix_sort_pairs(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(), keys2.as<uint64_t>(),
+                               vals2.as<uint32_t>(), n, bits_for(ncell - 1), st, &in_tmp));
+    const uint64_t *sk = in_tmp ? keys2.as<uint64_t>() : keys.as<uint64_t>();
+    const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
+    hipLaunchKernelGGL(k_segment_heads, dim3(blocks_for(n, 256)), dim3(256), 0, st, sk, n, flags.as<uint8_t>());
+    int64_t m = 0;
+    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), n, heads.as<int32_t>(), &m, st));
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_voxel_reduce<float>, dim3(blocks_for(m, 256)), dim3(256), 0, st, (const float *)xyz_dev,
+                           normals_dev, colors_dev, sk, sv, heads.as<int32_t>(), m, n, gp, out_xyz_dev,
+                           out_normals_dev, out_colors_dev, out_count_dev, out_ijk_dev);
+    else
+        hipLaunchKernelGGL(k_voxel_reduce<double>, dim3(blocks_for(m, 256)), dim3(256), 0, st,
+                           (const double *)xyz_dev, normals_dev, colors_dev, sk, sv, heads.as<int32_t>(), m, n, gp,
+                           out_xyz_dev, out_normals_dev, out_colors_dev, out_count_dev, out_ijk_dev);
+    PC_HIP(hipGetLastError());
+    PC_HIP(hipStreamSynchronize(st));  // scratch is released on return
+    *out_m = m;
+    return PC_OK;
+}
+
+int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double cell_size, int k_hint, pc_grid **out,
+                  void *stream) {
+    if (!ctx || !out || n < 0 || n >= INT32_MAX || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_grid_build");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *out = nullptr;
+    pc_grid *g = new (std::nothrow) pc_grid();
+    if (!g) return pc_fail(ctx, PC_NOMEM, "grid");
+    g->n = n;
+    g->dtype = dtype;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    int rc = bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st);
+    if (rc) {
+        delete g;
+        return rc;
+    }
+    double ext[3], emax = 0;
+    for (int a = 0; a < 3; a++) {
+        ext[a] = mx[a] - mn[a];
+        emax = std::max(emax, ext[a]);
+        g->gp.o[a] = mn[a];
+    }
+    double cell = cell_size;
+    if (!(cell > 0)) {
+        // about k/2 points per cell: the 3x3x3 block around a query then certifies most queries
+        double target = std::max(1.0, 0.5 * (double)std::max(1, k_hint));
+        double vol = 1.0;
+        for (int a = 0; a < 3; a++) vol *= std::max(ext[a], emax * 1e-3);
+        cell = (n > 0 && vol > 0) ? cbrt(vol * target / (double)n) : 1.0;
+        if (!(cell > 0) || !std::isfinite(cell)) cell = 1.0;
+    }
+    for (;;) {  // dense table capped at 8n + 4096 cells
+        double tot = 1.0;
+        for (int a = 0; a < 3; a++) {
+            double d = floor(ext[a] / cell) + 1.0;
+            d = std::min(d, 2.0e9);
+            g->gp.dim[a] = (int32_t)d;
+            tot *= d;
+        }
+        if (tot <= 8.0 * (double)n + 4096.0) break;
+        cell *= 1.25;
+    }
+    g->gp.cell = cell;
+    g->gp.s = 1.0 / cell;
+    g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
+
+    size_t rec_bytes = (dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64)) * (size_t)std::max<int64_t>(n, 1);
+    size_t cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
+    size_t perm_bytes = sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1);
+    g->rec = ctx->alloc(rec_bytes);
+    g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
+    g->perm = (int32_t *)ctx->alloc(perm_bytes);
+    g->bytes = rec_bytes + cs_bytes + perm_bytes;
+    if (!g->rec || !g->cell_start || !g->perm) {
+        pc_grid_destroy(ctx, g);
+        return pc_fail(ctx, PC_NOMEM, "grid buffers");
+    }
+    rc = PC_OK;
+    do {
+        if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
+            rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
+            break;
+        }
+        if (n == 0) break;
+        Scratch keys(ctx, sizeof(uint64_t) * (size_t)n), keys2(ctx, sizeof(uint64_t) * (size_t)n);
+        Scratch vals(ctx, sizeof(uint32_t) * (size_t)n), vals2(ctx, sizeof(uint32_t) * (size_t)n);
+        if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok()) {
+            rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
+            break;
+        }
+        if (dtype == PC_F32)
+            hipLaunchKernelGGL((k_cell_keys<float, false>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const float *)xyz_dev, n, g->gp, keys.as<uint64_t>(), vals.as<uint32_t>(),
+                               (int32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((k_cell_keys<double, false>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const double *)xyz_dev, n, g->gp, keys.as<uint64_t>(), vals.as<uint32_t>(),
+                               (int32_t *)nullptr);
+        // cell_start = exclusive scan of the per-cell counts
+        hipLaunchKernelGGL(k_cell_count, dim3(blocks_for(n, 256)), dim3(256), 0, st, keys.as<uint64_t>(), n,
+                           g->cell_start);
+        rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
+        if (rc) break;
+        bool in_tmp = false;
+        rc = pc_radix_sort_pairs(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(), keys2.as<uint64_t>(),
+                                 vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
+        if (rc) break;
+        const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
+        if (dtype == PC_F32)
+            hipLaunchKernelGGL((k_gather_records<float, Rec32>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const float *)xyz_dev, sv, n, (Rec32 *)g->rec, g->perm);
+        else
+            hipLaunchKernelGGL((k_gather_records<double, Rec64>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const double *)xyz_dev, sv, n, (Rec64 *)g->rec, g->perm);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            rc = pc_fail(ctx, PC_HIP_ERROR, "grid build kernels");
+    } while (0);
+    if (rc) {
+        pc_grid_destroy(ctx, g);
+        return rc;
+    }
+    *out = g;
+    return PC_OK;
+}
+
+void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
+    if (!g) return;
+    if (ctx) {
+        if (g->rec) ctx->release(g->rec);
+        if (g->cell_start) ctx->release(g->cell_start);
+        if (g->perm) ctx->release(g->perm);
+    }
+    delete g;
+}
+
+int pc_grid_info(const pc_grid *g, double info[6]) {
+    if (!g || !info) return PC_BAD_ARG;
+    info[0] = g->gp.dim[0];
+    info[1] = g->gp.dim[1];
+    info[2] = g->gp.dim[2];
+    info[3] = g->gp.cell;
+    info[4] = (double)g->n;
+    info[5] = (double)g->bytes;
+    return PC_OK;
+}
+
+const int32_t *pc_grid_perm_dev(const pc_grid *g) { return g ? g->perm : nullptr; }
+
+int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
+                   void *stream) {
+    if (!ctx || m < 0 || (m > 0 && (!src_dev || !idx_dev || !dst_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_gather_rows");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (m == 0) return PC_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(3 * m, 256)), dim3(256), 0, (hipStream_t)stream, src_dev,
+                       idx_dev, 3 * m, dst_dev);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// Stable LSD radix sort of (u64 key, u32 value) pairs, multi-block exclusive scan and ordered
+// stream compaction for gfx950.  All three are bandwidth-bound integer passes; no matrix work.
+#include "pc_common.h"
+
+namespace {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ROUNDS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;  // keys per block and pass
+constexpr int RADIX = 256;
+
+// ---- pass 1: per-block digit histogram ----------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n, int shift,
+                                                              uint32_t *__restrict__ block_hist, int nblocks) {
+    __shared__ uint32_t hist[RADIX];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+        int64_t i = base + (int64_t)r * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    block_hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];  // digit-major
+}
+
+// ---- pass 3: stable scatter ---------------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *__restrict__ keys,
+                                                                 const uint32_t *__restrict__ vals, int64_t n,
+                                                                 int shift, const uint32_t *__restrict__ block_off,
+                                                                 int nblocks, uint64_t *__restrict__ keys_out,
+                                                                 uint32_t *__restrict__ vals_out) {
+    __shared__ uint32_t run[RADIX];       // next output slot of each digit for this block
+    __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counts of the current round
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    run[tid] = block_off[(size_t)tid * nblocks + blockIdx.x];
+    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+        int64_t i = base + (int64_t)r * SORT_THREADS + tid;
+        bool valid = i < n;
+        if (base + (int64_t)r * SORT_THREADS >= n) break;  // uniform: whole round is past the end
+        uint64_t key = valid ? keys[i] : 0;
+        uint32_t val = valid ? vals[i] : 0;
+        uint32_t d = (uint32_t)(key >> shift) & (RADIX - 1);
+        // lanes of this wave holding the same digit
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        uint32_t rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+        if (valid && rank_in_wave == 0) wcnt[wave][d] = __popcll(m);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = run[d] + rank_in_wave;
+            for (int w = 0; w < wave; w++) pos += wcnt[w][d];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        {
+            uint32_t add = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                add += wcnt[w][tid];
+                wcnt[w][tid] = 0;
+            }
+            run[tid] += add;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- multi-block exclusive scan (u32) ----------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *lds /*[4]*/) {
+    // inclusive wave scan with shuffles
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        uint32_t c = lds[w];
+        if (w < wave) woff += c;
+        tot += c;
+    }
+    __syncthreads();
+    if (total) *total = tot;
+    return woff + x - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint32_t *__restrict__ data, int64_t n,
+                                                                   uint32_t *__restrict__ sums) {
+    __shared__ uint32_t lds[4];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++)
+        if (base + j < n) s += data[base + j];
+    uint32_t tot;
+    block_exclusive_scan(s, &tot, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// one block scans up to a few hundred thousand block sums in place
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t *__restrict__ data, int64_t n) {
+    __shared__ uint32_t part[1024];
+    int64_t per = (n + 1023) / 1024;
+    int64_t b = (int64_t)threadIdx.x * per, e = b + per < n ? b + per : n;
+    uint32_t s = 0;
+    for (int64_t i = b; i < e; i++) s += data[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 1024; i++) {
+            uint32_t t = part[i];
+            part[i] = acc;
+            acc += t;
+        }
+    }
+    __syncthreads();
+    uint32_t acc = part[threadIdx.x];
+    for (int64_t i = b; i < e; i++) {
+        uint32_t t = data[i];
+        data[i] = acc;
+        acc += t;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *__restrict__ data, int64_t n,
+                                                              const uint32_t *__restrict__ sums) {
+    __shared__ uint32_t lds[4];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        v[j] = base + j < n ? data[base + j] : 0;
+        s += v[j];
+    }
+    uint32_t off = block_exclusive_scan(s, nullptr, lds) + sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        if (base + j < n) data[base + j] = off;
+        off += v[j];
+    }
+}
+
+// ---- ordered compaction ----------------------------------------------------------------------
+constexpr int CMP_THREADS = 256;
+constexpr int CMP_ITEMS = 8;
+constexpr int CMP_TILE = CMP_THREADS * CMP_ITEMS;
+
+__global__ __launch_bounds__(CMP_THREADS) void k_compact_count(const uint8_t *__restrict__ flags, int64_t n,
+                                                                uint32_t *__restrict__ counts) {
+    __shared__ uint32_t lds[4];
+    int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; j++)
+        if (base + j < n) s += flags[base + j] ? 1u : 0u;
+    uint32_t tot;
+    block_exclusive_scan(s, &tot, lds);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *__restrict__ flags, int64_t n,
+                                                                const uint32_t *__restrict__ offsets,
+                                                                int32_t *__restrict__ out) {
+    __shared__ uint32_t lds[4];
+    int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    uint32_t s = 0;
+    uint8_t f[CMP_ITEMS];
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; j++) {
+        f[j] = base + j < n ? flags[base + j] : 0;
+        s += f[j] ? 1u : 0u;
+    }
+    uint32_t off = block_exclusive_scan(s, nullptr, lds) + offsets[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < CMP_ITEMS; j++)
+        if (f[j]) out[off++] = (int32_t)(base + j);
+}
+
+}  // namespace
+
+int pc_exclusive_scan_u32(pc_ctx *ctx, uint32_t *data, int64_t n, hipStream_t st) {
+    if (n <= 0) return PC_OK;
+    int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    Scratch sums(ctx, sizeof(uint32_t) * (size_t)nb);
+    if (!sums.ok()) return pc_fail(ctx, PC_NOMEM, "scan scratch");
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, data, n,
+                       sums.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, sums.as<uint32_t>(), nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, data, n, sums.as<uint32_t>());
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
+                        int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp) {
+    *result_in_tmp = false;
+    if (n <= 1) return PC_OK;
+    if (key_bits < 1) key_bits = 1;
+    int passes = (key_bits + 7) / 8;
+    int nblocks = (int)((n + SORT_TILE - 1) / SORT_TILE);
+    Scratch hist(ctx, sizeof(uint32_t) * (size_t)RADIX * (size_t)nblocks);
+    if (!hist.ok()) return pc_fail(ctx, PC_NOMEM, "radix histogram");
+    uint64_t *kin = keys, *kout = keys_tmp;
+    uint32_t *vin = vals, *vout = vals_tmp;
+    for (int p = 0; p < passes; p++) {
+        int shift = 8 * p;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, n, shift,
+                           hist.as<uint32_t>(), nblocks);
+        PC_TRY(pc_exclusive_scan_u32(ctx, hist.as<uint32_t>(), (int64_t)RADIX * nblocks, st));
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, vin, n, shift,
+                           hist.as<uint32_t>(), nblocks, kout, vout);
+        uint64_t *tk = kin;
+        kin = kout;
+        kout = tk;
+        uint32_t *tv = vin;
+        vin = vout;
+        vout = tv;
+    }
+    PC_HIP(hipGetLastError());
+    *result_in_tmp = (kin != keys);
+    return PC_OK;
+}
+
+int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_idx, int64_t *count,
+                     hipStream_t st) {
+    *count = 0;
+    if (n <= 0) return PC_OK;
+    int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
+    Scratch counts(ctx, sizeof(uint32_t) * (size_t)(nb + 1));
+    if (!counts.ok()) return pc_fail(ctx, PC_NOMEM, "compaction scratch");
+    uint32_t *c = counts.as<uint32_t>();
+    PC_HIP(hipMemsetAsync(c + nb, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c);
+    PC_TRY(pc_exclusive_scan_u32(ctx, c, nb + 1, st));  // c[nb] becomes the total
+    if (out_idx) hipLaunchKernelGGL(k_compact_write, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c, out_idx);
+    PC_HIP(hipGetLastError());
+    uint32_t total = 0;
+    PC_HIP(hipMemcpyAsync(&total, c + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    *count = (int64_t)total;
+    return PC_OK;
+}

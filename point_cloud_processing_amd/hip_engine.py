@@ -1,0 +1,254 @@
+"""The production engine: PointCloud methods -> C ABI -> HIP kernels on one MI355X.
+
+PyTorch is used for device memory (tensors as buffers), the current stream and nothing else;
+every computation is a kernel of libpc_amd.so.  Construction raises when the library or a
+GPU is missing: there is deliberately no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class DeviceGrid:
+    """Owns a pc_grid handle (the radix-sorted uniform grid of one cloud)."""
+
+    def __init__(self, eng: "HipEngine", xyz: torch.Tensor, n: int, k_hint: int, cell: float = 0.0):
+        self.eng = eng
+        self.xyz = xyz  # keep the coordinates alive as long as the grid
+        self.n = n
+        h = C.c_void_p()
+        dtype = _lib.PC_F32 if xyz.dtype == torch.float32 else _lib.PC_F64
+        eng._check(eng.lib.pc_grid_build(eng.ctx, _ptr(xyz), dtype, n, float(cell), int(k_hint), C.byref(h),
+                                         eng.stream()), "pc_grid_build")
+        self.h = h
+        self.k_hint = k_hint
+
+    def info(self):
+        out = (C.c_double * 6)()
+        self.eng.lib.pc_grid_info(self.h, out)
+        return {"dims": (int(out[0]), int(out[1]), int(out[2])), "cell": out[3], "n": int(out[4]),
+                "bytes": int(out[5])}
+
+    def close(self):
+        if self.h:
+            self.eng.lib.pc_grid_destroy(self.eng.ctx, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipEngine:
+    name = "hip"
+
+    def __init__(self, device: Optional[int] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("[pc_amd] no AMD GPU visible to PyTorch-ROCm; the neighbourhood stage has no CPU path")
+        if device is None:
+            device = int(os.environ.get("PC_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            device = device % torch.cuda.device_count()
+        self.device = torch.device("cuda", device)
+        ctx = C.c_void_p()
+        rc = self.lib.pc_create(device, C.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(f"[pc_amd] pc_create({device}) failed: {self.lib.pc_status_string(rc).decode()}")
+        self.ctx = ctx
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.pc_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        _lib.check(self.lib, self.ctx, rc, what)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def upload(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def dev_points(self, pts: np.ndarray, cache: dict) -> torch.Tensor:
+        """Device copy of a cloud's coordinates.  fp32 storage when every coordinate is
+        exactly fp32-representable (then nothing is lost), fp64 otherwise."""
+        t = cache.get("xyz")
+        if t is None:
+            p32 = pts.astype(np.float32)
+            if np.array_equal(p32.astype(np.float64), pts):
+                t = self.upload(p32)
+            else:
+                t = self.upload(pts)
+            cache["xyz"] = t
+        return t
+
+    @staticmethod
+    def _dt(t: torch.Tensor) -> int:
+        return _lib.PC_F32 if t.dtype == torch.float32 else _lib.PC_F64
+
+    def grid(self, pts: np.ndarray, cache: dict, k_hint: int) -> DeviceGrid:
+        key = ("grid", 1 if k_hint <= 4 else (2 if k_hint <= 16 else 3))
+        g = cache.get(key)
+        if g is None:
+            g = DeviceGrid(self, self.dev_points(pts, cache), len(pts), k_hint)
+            cache[key] = g
+        return g
+
+    # -- engine interface ----------------------------------------------------------------------
+    def bbox(self, pts, cache):
+        b = cache.get("bbox")
+        if b is None:
+            t = self.dev_points(pts, cache)
+            mn = (C.c_double * 3)()
+            mx = (C.c_double * 3)()
+            self._check(self.lib.pc_bbox(self.ctx, _ptr(t), self._dt(t), len(pts), mn, mx, self.stream()), "pc_bbox")
+            b = (np.array(mn[:], dtype=np.float64), np.array(mx[:], dtype=np.float64))
+            cache["bbox"] = b
+        return b
+
+    def affine(self, pts, cache, t, s, c):
+        d = self.upload(np.asarray(pts, dtype=np.float64))
+        tt = None if t is None else (C.c_double * 3)(*[float(v) for v in t])
+        cc = (C.c_double * 3)(*[float(v) for v in (c if c is not None else (0.0, 0.0, 0.0))])
+        self._check(self.lib.pc_affine(self.ctx, _ptr(d), len(pts), tt, 0 if s is None else 1,
+                                       0.0 if s is None else float(s), cc, self.stream()), "pc_affine")
+        return d.cpu().numpy()
+
+    def voxel_downsample(self, pts, nrm, col, vs, cache):
+        n = len(pts)
+        t = self.dev_points(pts, cache)
+        dn = None if nrm is None else self.upload(nrm)
+        dc = None if col is None else self.upload(col)
+        op = self.empty((n, 3), torch.float64)
+        on = None if nrm is None else self.empty((n, 3), torch.float64)
+        oc = None if col is None else self.empty((n, 3), torch.float64)
+        m = C.c_int64(0)
+        self._check(self.lib.pc_voxel_downsample(self.ctx, _ptr(t), self._dt(t), _ptr(dn), _ptr(dc), n, float(vs),
+                                                 _ptr(op), _ptr(on), _ptr(oc), None, None, C.byref(m), self.stream()),
+                    "pc_voxel_downsample")
+        m = m.value
+        return (op[:m].cpu().numpy(), None if on is None else on[:m].cpu().numpy(),
+                None if oc is None else oc[:m].cpu().numpy())
+
+    def voxel_assign(self, pts, vs, cache=None):
+        cache = {} if cache is None else cache
+        n = len(pts)
+        t = self.dev_points(pts, cache)
+        ijk = self.empty((n, 3), torch.int32)
+        dims = (C.c_int32 * 3)()
+        self._check(self.lib.pc_voxel_assign(self.ctx, _ptr(t), self._dt(t), n, float(vs), _ptr(ijk), dims,
+                                             self.stream()), "pc_voxel_assign")
+        return ijk.cpu().numpy(), np.array(dims[:], dtype=np.int32)
+
+    def voxel_downsample_info(self, pts, vs, cache=None):
+        cache = {} if cache is None else cache
+        n = len(pts)
+        t = self.dev_points(pts, cache)
+        op = self.empty((n, 3), torch.float64)
+        cnt = self.empty((n,), torch.int32)
+        ijk = self.empty((n, 3), torch.int32)
+        m = C.c_int64(0)
+        self._check(self.lib.pc_voxel_downsample(self.ctx, _ptr(t), self._dt(t), None, None, n, float(vs), _ptr(op),
+                                                 None, None, _ptr(cnt), _ptr(ijk), C.byref(m), self.stream()),
+                    "pc_voxel_downsample")
+        m = m.value
+        return op[:m].cpu().numpy(), cnt[:m].cpu().numpy(), ijk[:m].cpu().numpy()
+
+    def knn(self, pts, q, k, radius, cache, d2_dtype=torch.float64):
+        g = self.grid(pts, cache, k)
+        nq = len(pts) if q is None else len(q)
+        idx = self.empty((nq, k), torch.int32)
+        d2 = self.empty((nq, k), d2_dtype)
+        cnt = self.empty((nq,), torch.int32)
+        dq = None
+        qdt = _lib.PC_F64
+        if q is not None:
+            q32 = q.astype(np.float32)
+            dq = self.upload(q32 if np.array_equal(q32.astype(np.float64), q) else q)
+            qdt = self._dt(dq)
+        self._check(self.lib.pc_knn(self.ctx, g.h, _ptr(dq), qdt, nq, int(k), float(radius), _ptr(idx), _ptr(d2),
+                                    self._dt(d2), _ptr(cnt), self.stream()), "pc_knn")
+        return idx.cpu().numpy(), d2.cpu().numpy(), cnt.cpu().numpy()
+
+    def sor_avg_dev(self, pts, k, cache) -> torch.Tensor:
+        key = ("sor_avg", k)
+        avg = cache.get(key)
+        if avg is None:
+            g = self.grid(pts, cache, k)
+            avg = self.empty((len(pts),), torch.float64)
+            self._check(self.lib.pc_sor_avg(self.ctx, g.h, 0, len(pts), int(k), _ptr(avg), self.stream()),
+                        "pc_sor_avg")
+            cache[key] = avg
+        return avg
+
+    def sor_stats(self, avg: torch.Tensor, std_ratio: float):
+        n = avg.numel()
+        s = C.c_double(0)
+        valid = C.c_int64(0)
+        self._check(self.lib.pc_sor_sum(self.ctx, _ptr(avg), n, C.byref(s), C.byref(valid), self.stream()),
+                    "pc_sor_sum")
+        if valid.value == 0:
+            return 0.0, 0.0, 0.0, 0
+        mean = s.value / valid.value
+        sq = C.c_double(0)
+        self._check(self.lib.pc_sor_sqsum(self.ctx, _ptr(avg), n, mean, C.byref(sq), self.stream()), "pc_sor_sqsum")
+        with np.errstate(divide="ignore", invalid="ignore"):
+            std = float(np.sqrt(np.float64(sq.value) / np.float64(valid.value - 1)))
+        return mean, std, mean + std_ratio * std, valid.value
+
+    def sor(self, pts, k, std_ratio, cache):
+        avg = self.sor_avg_dev(pts, k, cache)
+        mean, std, thr, valid = self.sor_stats(avg, std_ratio)
+        if valid == 0:
+            return np.zeros(0, dtype=np.int64)
+        n = avg.numel()
+        kept = self.empty((n,), torch.int32)
+        nk = C.c_int64(0)
+        self._check(self.lib.pc_sor_select(self.ctx, _ptr(avg), n, float(thr), None, _ptr(kept), C.byref(nk),
+                                           self.stream()), "pc_sor_select")
+        return kept[: nk.value].cpu().numpy().astype(np.int64)
+
+    def normals(self, pts, k, radius, prior, cache):
+        g = self.grid(pts, cache, k)
+        n = len(pts)
+        out = self.empty((n, 3), torch.float64)
+        dp = None if prior is None else self.upload(np.asarray(prior, dtype=np.float64))
+        self._check(self.lib.pc_normals(self.ctx, g.h, 0, n, int(k), float(radius), _ptr(dp), _ptr(out),
+                                        self.stream()), "pc_normals")
+        return out.cpu().numpy()
+
+    def radius_count(self, pts, radius, cache):
+        g = self.grid(pts, cache, 8)
+        n = len(pts)
+        cnt = self.empty((n,), torch.int32)
+        self._check(self.lib.pc_radius_count(self.ctx, g.h, None, _lib.PC_F64, 0, 0, n, float(radius), _ptr(cnt),
+                                             self.stream()), "pc_radius_count")
+        return cnt.cpu().numpy()
+
+    def nn_distance(self, pts, cache):
+        g = self.grid(pts, cache, 2)
+        n = len(pts)
+        out = self.empty((n,), torch.float64)
+        self._check(self.lib.pc_nn_distance(self.ctx, g.h, 0, n, _ptr(out), self.stream()), "pc_nn_distance")
+        return out.cpu().numpy()

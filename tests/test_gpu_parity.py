@@ -1,0 +1,216 @@
+"""GPU parity: every C-ABI entry point against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for indices, counts, voxel ids and masks; fp64 squared distances bit-exact
+(same operation order on both sides); centroids and mean distances <= 1e-12 relative
+(north_star asks 1e-5); normals <= 1e-4 rad up to sign (observed ~1e-12).
+"""
+import numpy as np
+import pytest
+
+import datasets as D
+
+pytestmark = pytest.mark.gpu
+
+CLOUDS = {
+    "uniform": lambda: D.uniform_cube(20000, 11),
+    "clusters": lambda: D.gaussian_clusters(15000, 12),
+    "sphere": lambda: D.bumpy_sphere(12000, 13),
+    "planes": lambda: D.planar_patches(20000, 14, extent=50.0, n_patches=10),
+    "lidar": lambda: D.lidar_frame(15)[::6],
+    "lattice": lambda: D.lattice(8),
+    "fp64": lambda: D.gaussian_clusters(8000, 16, fp32=False),
+}
+
+
+def angle_up_to_sign(a, b):
+    c = np.abs((a * b).sum(1)) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    return np.arccos(np.clip(c, -1, 1))
+
+
+@pytest.mark.parametrize("name", list(CLOUDS))
+@pytest.mark.parametrize("k", [1, 2, 16, 30])
+def test_knn_self(hip, oracle, name, k):
+    p = CLOUDS[name]()
+    idx, d2, cnt = hip.knn(p, None, k, -1.0, {})
+    ridx, rd2, rcnt = oracle.knn(p, None, k)
+    assert np.array_equal(cnt, rcnt)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
+
+
+def test_knn_brute_small(hip, oracle):
+    p = D.gaussian_clusters(3000, 21)
+    idx, d2, cnt = hip.knn(p, None, 20, -1.0, {})
+    ridx, rd2, rcnt = oracle.knn_brute(p, None, 20)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (1, 4), (2, 2), (5, 16), (17, 16), (40, 64)])
+def test_knn_fewer_points_than_k(hip, oracle, n, k):
+    p = D.uniform_cube(n, 30 + n)
+    idx, d2, cnt = hip.knn(p, None, k, -1.0, {})
+    ridx, rd2, rcnt = oracle.knn_brute(p, None, k)
+    assert np.array_equal(cnt, np.full(n, min(n, k)))
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_knn_duplicates_tie_lower_index(hip, oracle):
+    base = D.uniform_cube(500, 41)
+    p = np.concatenate([base, base[:200], base[:50]], axis=0)
+    idx, d2, cnt = hip.knn(p, None, 8, -1.0, {})
+    ridx, rd2, _ = oracle.knn_brute(p, None, 8)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    # a duplicated point's first neighbours are its copies in ascending index order
+    assert list(idx[0, :3]) == [0, 500, 700]
+
+
+def test_knn_external_queries_inside_and_outside(hip, oracle):
+    p = D.uniform_cube(20000, 51)
+    rng = np.random.default_rng(52)
+    q = np.concatenate([rng.random((3000, 3)), rng.random((500, 3)) * 3.0 - 1.0,
+                        np.array([[10.0, 10.0, 10.0], [-5.0, 0.5, 0.5]])])
+    q = q.astype(np.float32).astype(np.float64)
+    idx, d2, cnt = hip.knn(p, q, 5, -1.0, {})
+    ridx, rd2, rcnt = oracle.knn(p, q, 5)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+
+
+def test_knn_hybrid_radius(hip, oracle):
+    p = D.bumpy_sphere(12000, 61)
+    r = 0.004
+    idx, d2, cnt = hip.knn(p, None, 30, r, {})
+    ridx, rd2, rcnt = oracle.knn(p, None, 30, r)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    assert cnt.min() < 30 <= cnt.max()  # both the radius cut and the max_nn cut are exercised
+    assert (d2[idx >= 0] < r * r).all()
+
+
+def test_knn_f32_distance_output(hip, oracle):
+    import torch
+
+    p = D.uniform_cube(5000, 71)
+    idx, d2, cnt = hip.knn(p, None, 16, -1.0, {}, d2_dtype=torch.float32)
+    ridx, rd2, _ = oracle.knn(p, None, 16)
+    assert np.array_equal(idx, ridx)
+    np.testing.assert_allclose(d2, rd2, rtol=1e-5)  # north_star: 1e-5 relative in fp32
+
+
+@pytest.mark.parametrize("name", ["uniform", "sphere", "planes", "fp64"])
+def test_voxel(hip, oracle, name):
+    p = CLOUDS[name]()
+    ext = (p.max(0) - p.min(0)).max()
+    for vs in (ext / 7.3, ext / 40.0):
+        ijk, dims = hip.voxel_assign(p, vs)
+        rijk, rdims, _ = oracle.voxel_index(p, vs)
+        assert np.array_equal(ijk, rijk) and np.array_equal(dims, rdims)
+        c, cnt, vijk = hip.voxel_downsample_info(p, vs)
+        rc, _, _, rcnt, rvijk = oracle.voxel_downsample(p, vs, with_info=True)
+        assert np.array_equal(vijk, rvijk) and np.array_equal(cnt, rcnt)
+        assert np.array_equal(c, rc)  # same summation order -> identical centroids
+
+
+def test_voxel_with_normals_colors(hip, oracle):
+    p = D.uniform_cube(5000, 81)
+    rng = np.random.default_rng(82)
+    nrm = rng.standard_normal((5000, 3))
+    col = rng.random((5000, 3))
+    a = hip.voxel_downsample(p, nrm, col, 0.05, {})
+    b = oracle.voxel_downsample(p, 0.05, nrm, col)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_voxel_bad_size(hip):
+    from point_cloud_processing_amd._lib import PcError
+
+    p = D.uniform_cube(100, 83)
+    with pytest.raises(RuntimeError):
+        hip.voxel_downsample(p, None, None, 0.0, {})
+    with pytest.raises(PcError, match="too small"):
+        hip.voxel_downsample(p * 1e6, None, None, 1e-7, {})
+
+
+@pytest.mark.parametrize("name", ["uniform", "clusters", "sphere", "lattice"])
+@pytest.mark.parametrize("k,sr", [(20, 2.0), (30, 3.0)])
+def test_sor(hip, oracle, name, k, sr):
+    p = CLOUDS[name]()
+    cache = {}
+    kept = hip.sor(p, k, sr, cache)
+    rkept, ravg, rstats = oracle.sor(p, k, sr)
+    avg = cache[("sor_avg", k)].cpu().numpy()
+    np.testing.assert_allclose(avg, ravg, rtol=1e-13, atol=0)
+    mean, std, thr, valid = hip.sor_stats(cache[("sor_avg", k)], sr)
+    assert valid == int(rstats[3])
+    np.testing.assert_allclose([mean, std, thr], rstats[:3], rtol=1e-12)
+    assert np.array_equal(kept, rkept)
+
+
+@pytest.mark.parametrize("name", ["uniform", "sphere", "planes", "lidar", "fp64"])
+def test_normals_knn(hip, oracle, name):
+    p = CLOUDS[name]()
+    n = hip.normals(p, 30, -1.0, None, {})
+    rn = oracle.normals(p, 30)
+    np.testing.assert_allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-12)
+    assert angle_up_to_sign(n, rn).max() < 1e-4
+    assert np.abs(n - rn).max() < 1e-6  # same sign convention too
+
+
+def test_normals_hybrid_and_prior(hip, oracle):
+    p = D.bumpy_sphere(12000, 91)
+    r = 0.02 * (p.max(0) - p.min(0)).max()
+    n = hip.normals(p, 30, r, None, {})
+    rn = oracle.normals(p, 30, r)
+    assert angle_up_to_sign(n, rn).max() < 1e-4 and np.abs(n - rn).max() < 1e-6
+    prior = p - p.mean(0)
+    n2 = hip.normals(p, 30, r, prior, {})
+    rn2 = oracle.normals(p, 30, r, prior)
+    assert np.abs(n2 - rn2).max() < 1e-6
+    assert ((n2 * prior).sum(1) >= 0).all()
+
+
+def test_normals_degenerate(hip, oracle):
+    # isolated points (fewer than 3 neighbours inside the radius) -> (0, 0, 1)
+    p = D.uniform_cube(200, 92) * 100.0
+    n = hip.normals(p, 30, 0.01, None, {})
+    assert np.array_equal(n, np.tile([0.0, 0.0, 1.0], (200, 1)))
+    # exact plane z = 0 -> +-z ; points on a line -> whatever the closed form gives, same as oracle
+    rng = np.random.default_rng(93)
+    plane = np.concatenate([rng.random((1000, 2)), np.zeros((1000, 1))], axis=1)
+    n = hip.normals(plane, 16, -1.0, None, {})
+    assert np.allclose(np.abs(n[:, 2]), 1.0, atol=1e-7)
+    line = np.stack([np.linspace(0, 1, 300)] * 3, -1)
+    assert np.abs(hip.normals(line, 10, -1.0, None, {}) - oracle.normals(line, 10)).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", ["uniform", "clusters", "sphere"])
+def test_radius_count_and_nn_distance(hip, oracle, name):
+    p = CLOUDS[name]()
+    nn = hip.nn_distance(p, {})
+    rnn = oracle.nn_distance(p)
+    assert np.array_equal(nn, rnn)
+    r = 5.0 * float(np.median(rnn))
+    assert np.array_equal(hip.radius_count(p, r, {}), oracle.radius_count(p, r))
+
+
+def test_radius_count_strict(hip):
+    p = np.array([[0.0, 0, 0], [1.0, 0, 0], [0, 2.0, 0]])
+    assert list(hip.radius_count(p, 1.0, {})) == [1, 1, 1]  # distance == r is not inside
+    assert list(hip.radius_count(p, 1.0000001, {})) == [2, 2, 1]
+    assert list(hip.nn_distance(p[:1], {})) == [0.0]
+
+
+def test_bbox_affine(hip, oracle):
+    p = D.gaussian_clusters(7000, 95, fp32=False)
+    mn, mx = hip.bbox(p, {})
+    assert np.array_equal(mn, p.min(0)) and np.array_equal(mx, p.max(0))
+    out, center, scale = oracle.normalize(p)
+    got = hip.affine(p, {}, -center, 1.0 / scale, np.zeros(3))
+    assert np.array_equal(got, out)
+
+
+def test_determinism(hip):
+    p = D.uniform_cube(30000, 97)
+    a = hip.knn(p, None, 16, -1.0, {})
+    b = hip.knn(p, None, 16, -1.0, {})
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(hip.normals(p, 16, -1.0, None, {}), hip.normals(p, 16, -1.0, None, {}))
