@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: exact kNN queries/s on a 10 M-point synthetic cloud, k = 16.
+
+One "step" = build the spatial index of the cloud (bounding box, cell keys, radix sort,
+cell table, record gather) + the exact self-kNN of every point (int32 indices + fp32 squared
+distances written to HBM).  The cloud is resident in HBM before the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  The global batch
+is N x 10 M queries over a replicated 10 M-point index; rank r answers shard r.  The kNN
+path has no exchange step, so there is no data-path collective: only the timing barrier and
+the MAX-reduce of the elapsed time use RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def knn_algorithmic_bytes(nq: int, n: int, k: int) -> int:
+    """12 B per query read + 12 B per reference point read once + (int32 idx + f32 d2) per neighbour."""
+    return 12 * nq + 12 * n + 8 * k * nq
+
+
+def cpu_baseline(points: np.ndarray, k: int, sample: int):
+    """The CPU oracle (C/OpenMP, grid-accelerated exact kNN, fp64) timed on this host."""
+    from oracle import pc_oracle as O
+
+    O.build()
+    n = len(points)
+    t0 = time.perf_counter()
+    g = O.Grid(points, target=4.0)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g.knn_self(k, 0, sample, want_d2=True)
+    t_query = time.perf_counter() - t0
+    value = sample / (t_build * (sample / n) + t_query)
+    return {
+        "value": value,
+        "unit": "queries/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"first {sample} of {n} cell-ordered self-queries, k={k}, against the full {n}-point grid; "
+                  f"grid build {t_build:.2f}s charged pro rata, query {t_query:.2f}s",
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the kNN+SOR+normals pipeline leg")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import datasets as D
+    from point_cloud_processing_amd import _lib
+    from point_cloud_processing_amd.hip_engine import HipEngine, _ptr
+
+    eng = HipEngine(local_rank)
+    lib, ctx = eng.lib, eng.ctx
+    n, k = args.points, args.k
+
+    pts64 = D.uniform_cube(n, 3)  # seed 3: the headline cloud
+    xyz = torch.from_numpy(pts64.astype(np.float32)).to(eng.device)  # resident, fp32-exact
+    out_idx = torch.empty((n, k), dtype=torch.int32, device=eng.device)
+    out_d2 = torch.empty((n, k), dtype=torch.float32, device=eng.device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(events=None):
+        h = C.c_void_p()
+        eng._check(lib.pc_grid_build(ctx, _ptr(xyz), _lib.PC_F32, n, 0.0, k, C.byref(h), eng.stream()), "grid")
+        if events:
+            events[0].record()
+        eng._check(lib.pc_knn(ctx, h, None, _lib.PC_F32, n, k, -1.0, _ptr(out_idx), _ptr(out_d2), _lib.PC_F32, None,
+                              eng.stream()), "knn")
+        if events:
+            events[1].record()
+        lib.pc_grid_destroy(ctx, h)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(ev[s])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n / (elapsed / args.steps)
+    alg = knn_algorithmic_bytes(n, n, k)
+    achieved = alg / (knn_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "kNN queries/sec (10M pts, k=16)",
+        "value": value,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"uniform [0,1)^3 cloud, {n} points (seed 3, fp32-representable), exact self-kNN k={k}; "
+                        "step = index build + kNN; per-rank batch = one full cloud over a replicated index",
+            "points": n,
+            "k": k,
+            "parallelism": f"query-shard x{world}, replicated index",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_scan<Rec32,float,M_KNN>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg,
+            "kernel_ms": knn_ms,
+            "kernel_queries_per_s": n / (knn_ms * 1e-3),
+        },
+    }
+
+    if rank == 0 and not args.no_pipeline:
+        # kNN(16) + statistical outlier removal + PCA normals on the same cloud (fused consumers)
+        avg = torch.empty((n,), dtype=torch.float64, device=eng.device)
+        nrm = torch.empty((n, 3), dtype=torch.float64, device=eng.device)
+        kept = torch.empty((n,), dtype=torch.int32, device=eng.device)
+
+        def pipeline():
+            h = C.c_void_p()
+            eng._check(lib.pc_grid_build(ctx, _ptr(xyz), _lib.PC_F32, n, 0.0, k, C.byref(h), eng.stream()), "grid")
+            eng._check(lib.pc_knn(ctx, h, None, _lib.PC_F32, n, k, -1.0, _ptr(out_idx), _ptr(out_d2), _lib.PC_F32,
+                                  None, eng.stream()), "knn")
+            eng._check(lib.pc_sor_avg(ctx, h, 0, n, k, _ptr(avg), eng.stream()), "sor_avg")
+            mean, std, thr, valid = eng.sor_stats(avg, 2.0)
+            nk = C.c_int64(0)
+            eng._check(lib.pc_sor_select(ctx, _ptr(avg), n, thr, None, _ptr(kept), C.byref(nk), eng.stream()), "sel")
+            eng._check(lib.pc_normals(ctx, h, 0, n, k, -1.0, None, _ptr(nrm), eng.stream()), "normals")
+            lib.pc_grid_destroy(ctx, h)
+            return nk.value
+
+        pipeline()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = max(1, min(3, args.steps))
+        for _ in range(reps):
+            nk = pipeline()
+        torch.cuda.synchronize()
+        pt = (time.perf_counter() - t0) / reps
+        result["pipeline"] = {
+            "what": f"index build + kNN({k}) + SOR(k={k}, std 2.0: avg, stats, select) + normals(knn={k})",
+            "points_per_s": n / pt,
+            "ms": pt * 1e3,
+            "kept": int(nk),
+            "algorithmic_bytes_per_point": 169,
+            "hbm_frac": 169.0 * n / pt / 1e9 / HBM_PEAK_GBS,
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(pts64, k, min(args.cpu_sample, n))
+        result["speedup_vs_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -437,6 +437,36 @@ ORC_API int orc_grid_knn(const void *h, const double *q, int64_t nq, int k, doub
     return err ? ORC_NOMEM : ORC_OK;
 }
 
+/* Self-query of every grid point, visiting the points in cell order (cache-friendly: this is
+ * the variant the CPU baseline times); row i of the outputs belongs to original point i. */
+ORC_API int orc_grid_knn_self(const void *h, int64_t s_begin, int64_t s_end, int k, double radius2,
+                              int32_t *out_idx, double *out_d2, int32_t *out_cnt) {
+    const orc_grid *g = (const orc_grid *)h;
+    if (!g || k < 1 || s_begin < 0 || s_end > g->n || s_end < s_begin) return ORC_BAD_ARG;
+    int err = 0;
+#pragma omp parallel
+    {
+        nb_t *L = (nb_t *)malloc(sizeof(nb_t) * (size_t)k);
+        if (!L) {
+#pragma omp atomic write
+            err = 1;
+        }
+#pragma omp for schedule(dynamic, 2048)
+        for (int64_t s = s_begin; s < s_end; s++) {
+            if (!L) continue;
+            int cnt = grid_query(g, g->sp + 3 * s, k, radius2, L, 0, NULL);
+            int64_t qi = g->perm[s];
+            for (int t = 0; t < k; t++) {
+                if (out_idx) out_idx[qi * k + t] = t < cnt ? L[t].i : -1;
+                if (out_d2) out_d2[qi * k + t] = t < cnt ? L[t].d : INFINITY;
+            }
+            if (out_cnt) out_cnt[qi] = cnt;
+        }
+        free(L);
+    }
+    return err ? ORC_NOMEM : ORC_OK;
+}
+
 /* remove_radius_outlier's neighbour count (filtering_adapter.py:94; upstream
  * PointCloud::RemoveRadiusOutliers over nanoflann radiusSearch): points with d2 < r*r,
  * strict, the point itself included. */

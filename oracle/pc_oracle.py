@@ -129,6 +129,18 @@ class Grid:
                                   _p(d2), _p(cnt)), "grid_knn")
         return idx, d2, cnt
 
+    def knn_self(self, k, s_begin=0, s_end=None, radius=None, want_d2=True):
+        """Self-query in cell order (the CPU-baseline variant); rows at original indices."""
+        n = len(self.pts)
+        s_end = n if s_end is None else s_end
+        idx = np.full((n, k), -1, dtype=np.int32)
+        d2 = np.full((n, k), np.inf, dtype=np.float64) if want_d2 else None
+        cnt = np.zeros(n, dtype=np.int32)
+        r2 = -1.0 if radius is None or radius < 0 else float(radius) * float(radius)
+        _check(lib().orc_grid_knn_self(C.c_void_p(self.h), C.c_int64(s_begin), C.c_int64(s_end), C.c_int(k),
+                                       C.c_double(r2), _p(idx), _p(d2), _p(cnt)), "grid_knn_self")
+        return idx, d2, cnt
+
     def radius_count(self, queries, radius):
         q = self.pts if queries is None else _pts(queries)
         cnt = np.empty(len(q), dtype=np.int32)
