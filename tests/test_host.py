@@ -1,0 +1,180 @@
+"""Host logic (the app/Core and app/Infrastructure mirrors and the PointCloud surface) on CPU,
+with the oracle engine injected.  Mirrors how the reference's callers use the boundary:
+reconstruction_controller.py:45-53 and app_controller.py:44-68."""
+import numpy as np
+import pytest
+
+import datasets as D
+import point_cloud_processing_amd as P
+from point_cloud_processing_amd.app.Core import estimate_bpa_radii, normalize_point_cloud, preprocess_point_cloud
+from point_cloud_processing_amd.app.Infrastructure import FilterSettings, filter_pcd
+
+pytestmark = pytest.mark.usefixtures("oracle_engine")
+
+
+def test_pointcloud_surface():
+    pts = D.uniform_cube(100, 1)
+    pcd = P.PointCloud()
+    pcd.points = P.Vector3dVector(pts)
+    assert len(pcd.points) == 100 and np.asarray(pcd.points).shape == (100, 3)
+    assert not pcd.has_normals() and not pcd.has_colors()
+    with pytest.raises(ValueError):
+        np.asarray(pcd.points)[0, 0] = 1.0  # views are read-only: caches stay valid
+    copy = P.PointCloud(pcd)  # copy-constructor, app_controller.py:49
+    copy.translate([1.0, 0, 0])
+    assert np.array_equal(np.asarray(pcd.points), pts)
+    assert np.array_equal(np.asarray(copy.points), pts + [1.0, 0, 0])
+    bbox = pcd.get_axis_aligned_bounding_box()
+    assert np.array_equal(bbox.get_center(), (pts.min(0) + pts.max(0)) * 0.5)
+    assert bbox.get_max_extent() == (pts.max(0) - pts.min(0)).max()
+    sel = pcd.select_by_index([5, 2, 7])
+    assert np.array_equal(np.asarray(sel.points), pts[[5, 2, 7]])
+    assert len(P.PointCloud().points) == 0 and P.PointCloud().get_axis_aligned_bounding_box().get_max_extent() == 0
+
+
+def test_normalize_mutates_and_returns_same_object(oracle):
+    pts = D.gaussian_clusters(3000, 2, fp32=False) * 100 + 1e4
+    pcd = P.PointCloud(pts)
+    out, center, scale = normalize_point_cloud(pcd)
+    assert out is pcd
+    ref, rc, rs = oracle.normalize(pts)
+    assert np.array_equal(np.asarray(pcd.points), ref) and np.array_equal(center, rc) and scale == rs
+    assert isinstance(center, np.ndarray) and center.shape == (3,) and isinstance(scale, float)
+    # all points identical: scale 0 -> only the translation happens
+    same = P.PointCloud(np.tile([[3.0, 4.0, 5.0]], (10, 1)))
+    _, c, s = normalize_point_cloud(same)
+    assert s == 0.0 and np.array_equal(np.asarray(same.points), np.zeros((10, 3)))
+
+
+def test_config1_small_object_plumbing(oracle, capsys):
+    """BASELINE config #1: ~35 k-point object through app/Core on CPU: normalise, voxel 0.005,
+    hybrid normals (2 % radius, max_nn 30), and SOR k=20 std=2.0."""
+    pts = D.bumpy_sphere(35000, 1)
+    pcd = P.PointCloud(pts)
+    pcd, center, scale = normalize_point_cloud(pcd)
+    proc = preprocess_point_cloud(pcd, voxel_size=0.005)
+    out = capsys.readouterr().out
+    assert "[Normalize] bbox center" in out and "[Preprocess] Voxel downsample with size = 0.005" in out
+    assert f"[Preprocess] Points: 35000 -> {len(proc.points)}" in out and "Estimating normals (radius=" in out
+    norm_pts, _, _ = oracle.normalize(pts)
+    vp, _, _ = oracle.voxel_downsample(norm_pts, 0.005)
+    assert proc is not pcd and np.array_equal(np.asarray(proc.points), vp)
+    radius = 0.02 * (vp.max(0) - vp.min(0)).max()
+    assert np.array_equal(np.asarray(proc.normals), oracle.normals(vp, 30, radius))
+    kept_cloud, kept = proc.remove_statistical_outlier(nb_neighbors=20, std_ratio=2.0)
+    rk, _, _ = oracle.sor(vp, 20, 2.0)
+    assert np.array_equal(kept, rk) and len(kept_cloud.points) == len(rk)
+    assert kept_cloud.has_normals()  # select_by_index carries normals
+    radii = estimate_bpa_radii(proc)
+    base = 1.5 * oracle.nn_distance(vp).mean()
+    assert radii == [base, base * 2.0, base * 3.0]
+
+
+def test_preprocess_without_voxel_returns_input_object():
+    pcd = P.PointCloud(D.bumpy_sphere(3000, 3))
+    for vs in (None, 0, -1.0):
+        out = preprocess_point_cloud(pcd, voxel_size=vs)
+        assert out is pcd and out.has_normals()
+
+
+def test_errors_match_open3d_types():
+    pcd = P.PointCloud(D.uniform_cube(100, 4))
+    with pytest.raises(RuntimeError):
+        pcd.voxel_down_sample(0.0)
+    with pytest.raises(RuntimeError):
+        pcd.remove_statistical_outlier(0, 2.0)
+    with pytest.raises(RuntimeError):
+        pcd.remove_statistical_outlier(10, 0.0)
+    with pytest.raises(RuntimeError):
+        pcd.remove_radius_outlier(0, 1.0)
+    assert P.PointCloud().remove_statistical_outlier(10, 1.0)[1] == []
+
+
+def test_filter_settings_fields():
+    s = FilterSettings()
+    assert (s.use_stat, s.use_radius, s.use_voxel, s.nb_stat, s.std_ratio, s.nb_radius, s.radius_mult, s.radius_abs,
+            s.voxel_mult, s.voxel_abs, s.max_drop, s.relax_iters, s.adaptive, s.debug) == (
+        True, True, False, 30, 3.0, 4, 5.0, None, 1.5, None, 0.30, 4, True, True)
+
+
+def _reference_filter(oracle, pts, s):
+    """Independent restatement of filtering_adapter.py:55-143 on raw arrays."""
+    n0 = len(pts)
+    nn_med = float(np.median(oracle.nn_distance(pts))) if (s.adaptive and n0 >= 10) else 0.0
+    if nn_med <= 0:
+        nn_med = 0.01
+    radius = s.radius_abs if s.radius_abs is not None else s.radius_mult * nn_med
+    voxel = (s.voxel_abs if s.voxel_abs is not None else s.voxel_mult * nn_med) if s.use_voxel else None
+
+    def run(sr, nb, r, allow):
+        cur = pts
+        if s.use_voxel and voxel and voxel > 0:
+            cur = oracle.voxel_downsample(cur, voxel)[0]
+        if s.use_stat:
+            cur = cur[oracle.sor(cur, s.nb_stat, sr)[0]]
+        if allow and s.use_radius and len(cur):
+            cur = cur[oracle.radius_count(cur, r) > nb]
+        return cur
+
+    cl = run(s.std_ratio, s.nb_radius, radius, True)
+    drop = 1 - len(cl) / n0
+    it = 0
+    used = 0
+    while drop > s.max_drop and it < s.relax_iters:
+        it += 1
+        t = run(s.std_ratio + 0.8 * it, max(2, s.nb_radius - it), radius * 1.35 ** it, True)
+        d = 1 - len(t) / n0
+        if d < drop:
+            cl, drop, used = t, d, it
+    if drop > s.max_drop and s.use_radius:
+        t = run(max(s.std_ratio, 3.5), s.nb_radius, radius, False)
+        d = 1 - len(t) / n0
+        if d <= drop:
+            cl, drop, used = t, d, -1
+    return cl, used
+
+
+@pytest.mark.parametrize("case", ["default", "relax", "voxel", "stat_only"])
+def test_filter_pcd_control_flow(oracle, case, capsys):
+    rng = np.random.default_rng(5)
+    if case == "relax":
+        # sparse halo around a dense core: the radius filter over-removes and the relax loop runs
+        pts = np.concatenate([D.uniform_cube(9000, 5) * 0.2, rng.random((3000, 3)) * 6.0])
+        s = FilterSettings(max_drop=0.05)
+    elif case == "voxel":
+        pts = np.concatenate([D.bumpy_sphere(6000, 6), rng.random((60, 3)) * 0.3])
+        s = FilterSettings(use_voxel=True)
+    elif case == "stat_only":
+        pts = np.concatenate([D.bumpy_sphere(6000, 7), rng.random((60, 3)) * 0.3])
+        s = FilterSettings(use_radius=False, adaptive=False, radius_abs=0.01)
+    else:
+        pts = np.concatenate([D.bumpy_sphere(8000, 8), rng.random((80, 3)) * 0.3])
+        s = None
+    pts = pts.astype(np.float32).astype(np.float64)
+    out = filter_pcd(P.PointCloud(pts), s)
+    ref, used = _reference_filter(oracle, pts, s or FilterSettings())
+    assert np.array_equal(np.asarray(out.points), ref)
+    text = capsys.readouterr().out
+    assert f"[Filter] n0={len(pts)} -> n={len(ref)}" in text
+    if case == "relax":
+        assert used != 0  # a relaxed attempt (or the stat-only fallback) won
+    if case == "default":
+        assert 0 < len(pts) - len(ref) < 0.3 * len(pts)
+
+
+def test_filter_pcd_empty_returns_input_object():
+    pcd = P.PointCloud()
+    assert filter_pcd(pcd) is pcd
+
+
+def test_filter_pcd_accepts_foreign_cloud_type():
+    class Foreign:  # stands in for o3d.geometry.PointCloud: only the attribute surface
+        def __init__(self):
+            self.points = P.Vector3dVector()
+            self.normals = P.Vector3dVector()
+            self.colors = P.Vector3dVector()
+
+    f = Foreign()
+    f.points = P.Vector3dVector(D.bumpy_sphere(3000, 9))
+    out = filter_pcd(f, FilterSettings(debug=False))
+    assert isinstance(out, Foreign) and 0 < len(out.points) <= 3000
