@@ -459,8 +459,11 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
     }
     double cell = cell_size;
     if (!(cell > 0)) {
-        // about k/2 points per cell: the 3x3x3 block around a query then certifies most queries
-        double target = std::max(1.0, 0.5 * (double)std::max(1, k_hint));
+        // cell edge ~ the 99.5 % quantile of the k-th neighbour distance in a uniform cloud
+        // (the ball then holds k + 2.6 sqrt(k) + 1 points): one ring of cells around a query's
+        // cell certifies almost every query
+        const double kk = (double)std::max(1, k_hint);
+        double target = std::max(1.0, 0.2387 * (kk + 2.6 * sqrt(kk) + 1.0));
         double vol = 1.0;
         for (int a = 0; a < 3; a++) vol *= std::max(ext[a], emax * 1e-3);
         cell = (n > 0 && vol > 0) ? cbrt(vol * target / (double)n) : 1.0;

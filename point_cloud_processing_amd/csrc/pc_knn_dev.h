@@ -1,0 +1,314 @@
+// Device-side helpers shared by the neighbour-search kernels: record loads, the closed-form
+// symmetric 3x3 eigen-solver and the per-query consumers (mean distance, normal, ...).
+#pragma once
+#include <math.h>
+
+#include "pc_common.h"
+
+enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4 };
+
+struct ScanArgs {
+    GridParams gp;
+    const void *rec;
+    const uint32_t *cell_start;
+    const void *queries;  // NULL: self-query over sorted positions
+    int64_t s_begin;      // first sorted position (self) / first query row (external)
+    int64_t nq;
+    int k;
+    double radius2;  // < 0: none
+    // outputs
+    int32_t *out_idx;
+    void *out_d2;
+    int d2_f64;
+    int32_t *out_cnt;
+    double *out_f64;        // SOR avg / NN distance / normals
+    const double *prior;    // normals only
+    // optional explicit list of sorted positions to answer (the exact re-run of queries that
+    // the tile kernel could not certify); *qcount entries of qlist
+    const int32_t *qlist;
+    const uint32_t *qcount;
+    // tile kernel only
+    int tile[3];            // tile edge in cells
+    int ntile[3];           // tiles per axis
+    int64_t s_end;          // self-query range end (sorted position)
+    int32_t *flag_list;     // queries handed to the exact re-run
+    uint32_t *flag_count;
+    uint32_t flag_cap;
+};
+
+template <typename REC>
+struct RecTraits;
+template <>
+struct RecTraits<Rec32> {
+    __device__ static inline void load(const Rec32 *p, double &x, double &y, double &z, int32_t &idx) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        x = (double)v.x;
+        y = (double)v.y;
+        z = (double)v.z;
+        idx = __float_as_int(v.w);
+    }
+};
+template <>
+struct RecTraits<Rec64> {
+    __device__ static inline void load(const Rec64 *p, double &x, double &y, double &z, int32_t &idx) {
+        const double2 a = *reinterpret_cast<const double2 *>(p);
+        const double2 b = *(reinterpret_cast<const double2 *>(p) + 1);
+        x = a.x;
+        y = a.y;
+        z = b.x;
+        idx = (int32_t)__double_as_longlong(b.y);
+    }
+};
+
+// ---- closed-form symmetric 3x3 eigen-solver (smallest-eigenvalue eigenvector) ---------------------
+// Same operation order as Open3D's FastEigen3x3 (after Eberly's RobustEigenSymmetric3x3).
+__device__ inline void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ inline double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ inline void eigvec0(const double A[6], double ev, double o[3]) {
+    double r0[3] = {A[0] - ev, A[1], A[2]};
+    double r1[3] = {A[1], A[3] - ev, A[4]};
+    double r2[3] = {A[2], A[4], A[5] - ev};
+    double c01[3], c02[3], c12[3];
+    cross3(r0, r1, c01);
+    cross3(r0, r2, c02);
+    cross3(r1, r2, c12);
+    double d0 = dot3(c01, c01), d1 = dot3(c02, c02), d2 = dot3(c12, c12);
+    double dmax = d0;
+    int imax = 0;
+    if (d1 > dmax) {
+        dmax = d1;
+        imax = 1;
+    }
+    if (d2 > dmax) imax = 2;
+    double s = sqrt(imax == 0 ? d0 : (imax == 1 ? d1 : d2));
+#pragma unroll
+    for (int a = 0; a < 3; a++) o[a] = (imax == 0 ? c01[a] : (imax == 1 ? c02[a] : c12[a])) / s;
+}
+
+__device__ inline void eigvec1(const double A[6], const double e0[3], double ev, double o[3]) {
+    double U[3], V[3];
+    if (fabs(e0[0]) > fabs(e0[1])) {
+        double il = 1 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
+        U[0] = -e0[2] * il;
+        U[1] = 0;
+        U[2] = e0[0] * il;
+    } else {
+        double il = 1 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
+        U[0] = 0;
+        U[1] = e0[2] * il;
+        U[2] = -e0[1] * il;
+    }
+    cross3(e0, U, V);
+    double AU[3] = {A[0] * U[0] + A[1] * U[1] + A[2] * U[2], A[1] * U[0] + A[3] * U[1] + A[4] * U[2],
+                    A[2] * U[0] + A[4] * U[1] + A[5] * U[2]};
+    double AV[3] = {A[0] * V[0] + A[1] * V[1] + A[2] * V[2], A[1] * V[0] + A[3] * V[1] + A[4] * V[2],
+                    A[2] * V[0] + A[4] * V[1] + A[5] * V[2]};
+    double m00 = U[0] * AU[0] + U[1] * AU[1] + U[2] * AU[2] - ev;
+    double m01 = U[0] * AV[0] + U[1] * AV[1] + U[2] * AV[2];
+    double m11 = V[0] * AV[0] + V[1] * AV[1] + V[2] * AV[2] - ev;
+    double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        double mx = a00 > a01 ? a00 : a01;
+        if (mx > 0) {
+            if (a00 >= a01) {
+                m01 /= m00;
+                m00 = 1 / sqrt(1 + m01 * m01);
+                m01 *= m00;
+            } else {
+                m00 /= m01;
+                m01 = 1 / sqrt(1 + m00 * m00);
+                m00 *= m01;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) o[a] = m01 * U[a] - m00 * V[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; a++) o[a] = U[a];
+        }
+    } else {
+        double mx = a11 > a01 ? a11 : a01;
+        if (mx > 0) {
+            if (a11 >= a01) {
+                m01 /= m11;
+                m11 = 1 / sqrt(1 + m01 * m01);
+                m01 *= m11;
+            } else {
+                m11 /= m01;
+                m01 = 1 / sqrt(1 + m11 * m11);
+                m11 *= m01;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) o[a] = m11 * U[a] - m01 * V[a];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; a++) o[a] = U[a];
+        }
+    }
+}
+
+// cov = {c00,c01,c02,c11,c12,c22}
+__device__ inline void fast_eigen3x3(const double cov[6], double out[3]) {
+    double A[6];
+    double mc = cov[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++)
+        if (cov[i] > mc) mc = cov[i];
+    if (mc == 0) {
+        out[0] = out[1] = out[2] = 0;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) A[i] = cov[i] / mc;
+    double norm = A[1] * A[1] + A[2] * A[2] + A[4] * A[4];
+    if (norm > 0) {
+        double q = (A[0] + A[3] + A[5]) / 3;
+        double b00 = A[0] - q, b11 = A[3] - q, b22 = A[5] - q;
+        double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
+        double c00 = b11 * b22 - A[4] * A[4];
+        double c01 = A[1] * b22 - A[4] * A[2];
+        double c02 = A[1] * A[4] - b11 * A[2];
+        double det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+        double hd = det * 0.5;
+        hd = fmin(fmax(hd, -1.0), 1.0);
+        double angle = acos(hd) / 3.0;
+        const double two_thirds_pi = 2.09439510239319549;
+        double beta2 = cos(angle) * 2;
+        double beta0 = cos(angle + two_thirds_pi) * 2;
+        double beta1 = -(beta0 + beta2);
+        double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;
+        double v0[3], v1[3], v2[3];
+        if (hd >= 0) {
+            eigvec0(A, e2, v2);
+            if (e2 < e0 && e2 < e1) {
+                out[0] = v2[0], out[1] = v2[1], out[2] = v2[2];
+                return;
+            }
+            eigvec1(A, v2, e1, v1);
+            if (e1 < e0 && e1 < e2) {
+                out[0] = v1[0], out[1] = v1[1], out[2] = v1[2];
+                return;
+            }
+            cross3(v1, v2, out);
+        } else {
+            eigvec0(A, e0, v0);
+            if (e0 < e1 && e0 < e2) {
+                out[0] = v0[0], out[1] = v0[1], out[2] = v0[2];
+                return;
+            }
+            eigvec1(A, v0, e1, v1);
+            if (e1 < e0 && e1 < e2) {
+                out[0] = v1[0], out[1] = v1[1], out[2] = v1[2];
+                return;
+            }
+            cross3(v0, v1, out);
+        }
+    } else {
+        double a0 = A[0] * mc, a1 = A[3] * mc, a2 = A[5] * mc;
+        out[0] = out[1] = out[2] = 0;
+        if (a0 < a1 && a0 < a2)
+            out[0] = 1;
+        else if (a1 < a0 && a1 < a2)
+            out[1] = 1;
+        else
+            out[2] = 1;
+    }
+}
+
+
+// ---- per-query consumers -------------------------------------------------------------------------
+// NB(s, d2, x, y, z, idx) yields the s-th nearest neighbour (ascending (d2, idx)) of this query.
+template <int MODE, typename NB>
+__device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, NB nb) {
+    const int k = A.k;
+    if (MODE == M_KNN) {
+        for (int s = 0; s < k; s++) {
+            int32_t id = -1;
+            double d = INFINITY, x, y, z;
+            if (s < cnt) nb(s, d, x, y, z, id);
+            if (A.out_idx) A.out_idx[out_row * k + s] = id;
+            if (A.out_d2) {
+                if (A.d2_f64)
+                    reinterpret_cast<double *>(A.out_d2)[out_row * k + s] = d;
+                else
+                    reinterpret_cast<float *>(A.out_d2)[out_row * k + s] = (float)d;
+            }
+        }
+        if (A.out_cnt) A.out_cnt[out_row] = cnt;
+    } else if (MODE == M_SOR) {
+        double m = -1.0;
+        if (cnt > 0) {
+            double sum = 0.0;
+            for (int s = 0; s < cnt; s++) {
+                double d, x, y, z;
+                int32_t id;
+                nb(s, d, x, y, z, id);
+                sum += sqrt(d);
+            }
+            m = sum / (double)cnt;
+        }
+        A.out_f64[out_row] = m;
+    } else if (MODE == M_NNDIST) {
+        double d = 0.0, x, y, z;
+        int32_t id;
+        if (cnt > 1) {
+            nb(1, d, x, y, z, id);
+            d = sqrt(d);
+        }
+        A.out_f64[out_row] = d;
+    } else if (MODE == M_NORMALS) {
+        double nv[3];
+        if (cnt >= 3) {
+            double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < cnt; s++) {
+                double d, px, py, pz;
+                int32_t id;
+                nb(s, d, px, py, pz, id);
+                cu[0] += px;
+                cu[1] += py;
+                cu[2] += pz;
+                cu[3] += px * px;
+                cu[4] += px * py;
+                cu[5] += px * pz;
+                cu[6] += py * py;
+                cu[7] += py * pz;
+                cu[8] += pz * pz;
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) cu[i] /= (double)cnt;
+            double cov[6];
+            cov[0] = cu[3] - cu[0] * cu[0];
+            cov[3] = cu[6] - cu[1] * cu[1];
+            cov[5] = cu[8] - cu[2] * cu[2];
+            cov[1] = cu[4] - cu[0] * cu[1];
+            cov[2] = cu[5] - cu[0] * cu[2];
+            cov[4] = cu[7] - cu[1] * cu[2];
+            fast_eigen3x3(cov, nv);
+        } else {
+            nv[0] = 0, nv[1] = 0, nv[2] = 1;  // identity covariance -> smallest-diagonal rule -> +z
+        }
+        const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        if (nn == 0.0) {
+            if (A.prior) {
+                nv[0] = A.prior[3 * out_row], nv[1] = A.prior[3 * out_row + 1], nv[2] = A.prior[3 * out_row + 2];
+            } else {
+                nv[0] = 0, nv[1] = 0, nv[2] = 1;
+            }
+        }
+        if (A.prior &&
+            nv[0] * A.prior[3 * out_row] + nv[1] * A.prior[3 * out_row + 1] + nv[2] * A.prior[3 * out_row + 2] < 0.0) {
+            nv[0] *= -1.0, nv[1] *= -1.0, nv[2] *= -1.0;
+        }
+        A.out_f64[3 * out_row] = nv[0];
+        A.out_f64[3 * out_row + 1] = nv[1];
+        A.out_f64[3 * out_row + 2] = nv[2];
+    }
+}
+
+// pc_knn_tile.hip: the tile-cooperative fast path (fp32 grids, self-queries, k <= 32).
+// Returns PC_OK after enqueueing; *handled = false when the configuration is not supported.
+int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled);
