@@ -174,13 +174,12 @@ def main() -> int:
         def pipeline():
             h = C.c_void_p()
             eng._check(lib.pc_grid_build(ctx, _ptr(xyz), _lib.PC_F32, n, 0.0, k, C.byref(h), eng.stream()), "grid")
-            eng._check(lib.pc_knn(ctx, h, None, _lib.PC_F32, n, k, -1.0, _ptr(out_idx), _ptr(out_d2), _lib.PC_F32,
-                                  None, eng.stream()), "knn")
-            eng._check(lib.pc_sor_avg(ctx, h, 0, n, k, _ptr(avg), eng.stream()), "sor_avg")
+            # one neighbour search feeds all three consumers
+            eng._check(lib.pc_knn_fused(ctx, h, 0, n, k, -1.0, _ptr(out_idx), _ptr(out_d2), _lib.PC_F32, None,
+                                        _ptr(avg), _ptr(nrm), None, eng.stream()), "knn_fused")
             mean, std, thr, valid = eng.sor_stats(avg, 2.0)
             nk = C.c_int64(0)
             eng._check(lib.pc_sor_select(ctx, _ptr(avg), n, thr, None, _ptr(kept), C.byref(nk), eng.stream()), "sel")
-            eng._check(lib.pc_normals(ctx, h, 0, n, k, -1.0, None, _ptr(nrm), eng.stream()), "normals")
             lib.pc_grid_destroy(ctx, h)
             return nk.value
 
@@ -193,7 +192,7 @@ def main() -> int:
         torch.cuda.synchronize()
         pt = (time.perf_counter() - t0) / reps
         result["pipeline"] = {
-            "what": f"index build + kNN({k}) + SOR(k={k}, std 2.0: avg, stats, select) + normals(knn={k})",
+            "what": f"index build + fused kNN({k}) -> rows + SOR(k={k}, std 2.0: avg, stats, select) + normals(knn={k})",
             "points_per_s": n / pt,
             "ms": pt * 1e3,
             "kept": int(nk),

@@ -108,6 +108,13 @@ int pc_knn_range(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_en
  * including the point itself, avg = sum(sqrt(d2)) / found, written at the original index. */
 int pc_sor_avg(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double *out_avg_dev,
                void *stream);
+/* One neighbour search, every consumer: kNN rows (out_idx / out_d2 / out_cnt), the SOR mean
+ * distance (out_avg) and the PCA normal (out_normals) of sorted positions [s_begin, s_end),
+ * each written at the original index; any output may be NULL.  Equals pc_knn_range +
+ * pc_sor_avg + pc_normals with the same k and radius, for a third of the search work. */
+int pc_knn_fused(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
+                 int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, double *out_avg_dev,
+                 double *out_normals_dev, const double *prior_dev, void *stream);
 /* Deterministic partial sums over avg[0..n): *sum_pos = sum of avg > 0, *n_valid = #(avg >= 0). */
 int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, int64_t *n_valid, void *stream);
 /* *sq = sum over avg > 0 of (avg - mean)^2. */

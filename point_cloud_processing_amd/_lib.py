@@ -35,6 +35,7 @@ SYMBOLS = [
     ("pc_knn", _i32, [_vp, _vp, _vp, _i32, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp]),
     ("pc_knn_range", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp]),
     ("pc_sor_avg", _i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    ("pc_knn_fused", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("pc_sor_sum", _i32, [_vp, _vp, _i64, _pd, _pi64, _vp]),
     ("pc_sor_sqsum", _i32, [_vp, _vp, _i64, _dbl, _pd, _vp]),
     ("pc_sor_select", _i32, [_vp, _vp, _i64, _dbl, _vp, _vp, _pi64, _vp]),

@@ -317,6 +317,27 @@ int pc_sor_avg(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end,
     return launch_scan<M_SOR>(ctx, grid, grid->dtype, A, (hipStream_t)stream);
 }
 
+int pc_knn_fused(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
+                 int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, double *out_avg_dev,
+                 double *out_normals_dev, const double *prior_dev, void *stream) {
+    if (!ctx || !grid || k < 1 || k > PC_MAX_K || !range_ok(grid, s_begin, s_end))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_knn_fused");
+    PC_HIP(hipSetDevice(ctx->device));
+    ScanArgs A = base_args(grid);
+    A.s_begin = s_begin;
+    A.nq = s_end - s_begin;
+    A.k = k;
+    A.radius2 = radius >= 0 ? radius * radius : -1.0;
+    A.out_idx = out_idx_dev;
+    A.out_d2 = out_d2_dev;
+    A.d2_f64 = d2_dtype == PC_F64;
+    A.out_cnt = out_cnt_dev;
+    A.out_f64 = out_avg_dev;
+    A.out_nrm = out_normals_dev;
+    A.prior = prior_dev;
+    return launch_scan<M_ALL>(ctx, grid, grid->dtype, A, (hipStream_t)stream);
+}
+
 int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, int64_t *n_valid, void *stream) {
     if (!ctx || n < 0 || (n > 0 && !avg_dev) || !sum_pos || !n_valid) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_sum");
     PC_HIP(hipSetDevice(ctx->device));

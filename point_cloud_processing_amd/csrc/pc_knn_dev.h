@@ -5,7 +5,7 @@
 
 #include "pc_common.h"
 
-enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4 };
+enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4, M_ALL = 5 };
 
 struct ScanArgs {
     GridParams gp;
@@ -22,6 +22,7 @@ struct ScanArgs {
     int d2_f64;
     int32_t *out_cnt;
     double *out_f64;        // SOR avg / NN distance / normals
+    double *out_nrm;        // normals of the fused mode (M_ALL), where out_f64 is the SOR average
     const double *prior;    // normals only
     // optional explicit list of sorted positions to answer (the exact re-run of queries that
     // the tile kernel could not certify); *qcount entries of qlist
@@ -31,6 +32,7 @@ struct ScanArgs {
     int tile[3];            // tile edge in cells
     int ntile[3];           // tiles per axis
     int64_t s_end;          // self-query range end (sorted position)
+    int cand_cap;           // candidates the LDS block holds
     int32_t *flag_list;     // queries handed to the exact re-run
     uint32_t *flag_count;
     uint32_t flag_cap;
@@ -225,7 +227,7 @@ __device__ inline void fast_eigen3x3(const double cov[6], double out[3]) {
 template <int MODE, typename NB>
 __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, NB nb) {
     const int k = A.k;
-    if (MODE == M_KNN) {
+    if ((MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
         for (int s = 0; s < k; s++) {
             int32_t id = -1;
             double d = INFINITY, x, y, z;
@@ -239,7 +241,8 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
             }
         }
         if (A.out_cnt) A.out_cnt[out_row] = cnt;
-    } else if (MODE == M_SOR) {
+    }
+    if (MODE == M_SOR || (MODE == M_ALL && A.out_f64)) {
         double m = -1.0;
         if (cnt > 0) {
             double sum = 0.0;
@@ -252,7 +255,8 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
             m = sum / (double)cnt;
         }
         A.out_f64[out_row] = m;
-    } else if (MODE == M_NNDIST) {
+    }
+    if (MODE == M_NNDIST) {
         double d = 0.0, x, y, z;
         int32_t id;
         if (cnt > 1) {
@@ -260,7 +264,9 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
             d = sqrt(d);
         }
         A.out_f64[out_row] = d;
-    } else if (MODE == M_NORMALS) {
+    }
+    if (MODE == M_NORMALS || (MODE == M_ALL && A.out_nrm)) {
+        double *out_n = MODE == M_ALL ? A.out_nrm : A.out_f64;
         double nv[3];
         if (cnt >= 3) {
             double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -303,9 +309,9 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
             nv[0] * A.prior[3 * out_row] + nv[1] * A.prior[3 * out_row + 1] + nv[2] * A.prior[3 * out_row + 2] < 0.0) {
             nv[0] *= -1.0, nv[1] *= -1.0, nv[2] *= -1.0;
         }
-        A.out_f64[3 * out_row] = nv[0];
-        A.out_f64[3 * out_row + 1] = nv[1];
-        A.out_f64[3 * out_row + 2] = nv[2];
+        out_n[3 * out_row] = nv[0];
+        out_n[3 * out_row + 1] = nv[1];
+        out_n[3 * out_row + 2] = nv[2];
     }
 }
 

@@ -20,10 +20,11 @@
 namespace {
 
 constexpr int ORD_BITS = 10;
-constexpr int CAND_CAP = 1 << ORD_BITS;  // candidates one tile may stage (16 KiB of LDS)
-constexpr uint32_t ORD_MASK = CAND_CAP - 1;
+constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may stage (16 KiB of LDS)
+constexpr uint32_t ORD_MASK = CAND_CAP_MAX - 1;
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr int MAX_ROWS = 64;  // (tile_y + 2) * (tile_z + 2) must fit one wave
+constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most
 
 __device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -41,8 +42,11 @@ __device__ inline void list_insert(uint32_t (&L)[KS], uint32_t key) {
 template <int KS, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *cand = reinterpret_cast<float4 *>(smem);                                          // [CAND_CAP]
-    uint16_t *ordbuf = reinterpret_cast<uint16_t *>(smem + sizeof(float4) * CAND_CAP);        // [k][64]
+    float4 *cand = reinterpret_cast<float4 *>(smem);                                               // [cand_cap]
+    uint32_t *row_src = reinterpret_cast<uint32_t *>(smem + sizeof(float4) * A.cand_cap);          // [64] begin
+    uint32_t *row_off = row_src + MAX_ROWS;                                                        // [65] offsets
+    uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_off + MAX_ROWS + 4);                     // [64][MAX_NX+1]
+    uint16_t *ordbuf = cell_off + MAX_ROWS * (MAX_NX + 1);                                         // [k][64]
     const int lane = threadIdx.x;
     const GridParams &gp = A.gp;
     const Rec32 *rec = reinterpret_cast<const Rec32 *>(A.rec);
@@ -91,24 +95,54 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             q_off += b;
         }
     }
-    const uint32_t ncand = __shfl(cand_off, 63, 64), nquery = __shfl(q_off, 63, 64);
+    const uint32_t ncand = __builtin_amdgcn_readfirstlane(__shfl(cand_off, 63, 64));
+    const uint32_t nquery = __builtin_amdgcn_readfirstlane(__shfl(q_off, 63, 64));
     if (nquery == 0) return;  // wave-uniform
     cand_off -= row_cnt;      // exclusive
     q_off -= q_cnt;
 
-    const bool overfull = ncand > (uint32_t)CAND_CAP;
+    const bool overfull = ncand > (uint32_t)A.cand_cap;
 
-    // ---- stage the candidate block into LDS (row by row, coalesced 16-byte records) ---------------
+    // ---- stage the candidate block into LDS ------------------------------------------------------
+    // flattened over the block's candidates: lane i copies candidates i, i+64, ...; the row of a
+    // candidate follows from the row offsets, and four 16-byte loads are in flight per lane
+    row_src[lane] = row_begin;
+    row_off[lane] = cand_off;
+    if (lane == 0) row_off[MAX_ROWS] = ncand;
+    __syncthreads();
     if (!overfull) {
-        for (int r = 0; r < nrows; r++) {
-            const uint32_t rb = __shfl(row_begin, r, 64), rc = __shfl(row_cnt, r, 64), ro = __shfl(cand_off, r, 64);
-            for (uint32_t i = lane; i < rc; i += PC_WAVE)
-                cand[ro + i] = *reinterpret_cast<const float4 *>(rec + rb + i);
+        int r = 0;
+        for (uint32_t base = 0; base < ncand; base += 4 * PC_WAVE) {
+            uint32_t src[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t i = base + b * PC_WAVE + lane;
+                src[b] = 0;
+                if (i < ncand) {
+                    while (r + 1 < nrows && i >= row_off[r + 1]) r++;
+                    src[b] = row_src[r] + (i - row_off[r]);
+                }
+            }
+            float4 v[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) v[b] = *reinterpret_cast<const float4 *>(rec + src[b]);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t i = base + b * PC_WAVE + lane;
+                if (i < ncand) cand[i] = v[b];
+            }
         }
+    }
+    // block-relative offset of every cell boundary of every block row
+    const int nx = hi[0] - lo[0] + 1;
+    for (int e = lane; e < nrows * (nx + 1); e += PC_WAVE) {
+        const int r = e / (nx + 1), i = e - r * (nx + 1);
+        const int y = lo[1] + r % nry, z = lo[2] + r / nry;
+        const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+        cell_off[r * (MAX_NX + 1) + i] = (uint16_t)(row_off[r] + (A.cell_start[row + lo[0] + i] - row_src[r]));
     }
     __syncthreads();
 
-    // certification geometry shared by all lanes: faces of the block that are not grid faces
     const double eps = 1e-7 * gp.cell;
     const double r2lim = A.radius2;
 
@@ -136,22 +170,63 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
 #pragma unroll
         for (int s = 0; s < KS; s++) L[s] = KEY_EMPTY;
 
-        // ---- stage 1: fp32 filter over the shared candidate sequence ------------------------------
-        uint32_t j = 0;
-        for (; j + 4 <= ncand; j += 4) {
-            const float4 a0 = cand[j], a1 = cand[j + 1], a2 = cand[j + 2], a3 = cand[j + 3];
+        // ---- stage 1: fp32 filter over the lane's own 3x3x3 cells --------------------------------
+        // Lanes of one cell walk the same LDS range (broadcast reads); the nine (dy, dz) row
+        // segments are visited in lock-step, each for the longest segment any lane has.
+        int qc[3];
+        {
+            const float qf[3] = {qx, qy, qz};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double tt = floor(((double)qf[a] - gp.o[a]) * gp.s);
+                qc[a] = !(tt > 0.0) ? 0 : (tt >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)tt);
+            }
+        }
+        const int i0 = max(qc[0] - 1, 0) - lo[0], i1 = min(qc[0] + 1, gp.dim[0] - 1) - lo[0] + 1;
 #define PC_KEY(a, jj)                                                                                   \
     ((__float_as_uint(fmaf(qz - a.z, qz - a.z, fmaf(qy - a.y, qy - a.y, (qx - a.x) * (qx - a.x)))) & ~ORD_MASK) | \
      (jj))
-            const uint32_t k0 = PC_KEY(a0, j), k1 = PC_KEY(a1, j + 1), k2 = PC_KEY(a2, j + 2), k3 = PC_KEY(a3, j + 3);
-            list_insert<KS>(L, k0);
-            list_insert<KS>(L, k1);
-            list_insert<KS>(L, k2);
-            list_insert<KS>(L, k3);
+        // the nine (start, length) pairs and the wave-wide longest length of each, up front:
+        // the nine max-reductions overlap instead of serialising in front of every segment
+        uint32_t seg_pack[9];  // start | len << 16
+        int seg_max[9];
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) {
+            const int y = qc[1] + seg % 3 - 1, z = qc[2] + seg / 3 - 1;
+            uint32_t st = 0, ln = 0;
+            if (active && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2]) {
+                const int r = (y - lo[1]) + nry * (z - lo[2]);
+                st = cell_off[r * (MAX_NX + 1) + i0];
+                ln = cell_off[r * (MAX_NX + 1) + i1] - st;
+            }
+            seg_pack[seg] = st | (ln << 16);
+            seg_max[seg] = (int)ln;
         }
-        for (; j < ncand; j++) {
-            const float4 a0 = cand[j];
-            list_insert<KS>(L, PC_KEY(a0, j));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int seg = 0; seg < 9; seg++) seg_max[seg] = max(seg_max[seg], __shfl_xor(seg_max[seg], o, 64));
+        }
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) seg_max[seg] = __builtin_amdgcn_readfirstlane(seg_max[seg]);
+        const uint32_t last = ncand - 1;
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) {
+            const uint32_t start = seg_pack[seg] & 0xffffu;
+            const int len = (int)(seg_pack[seg] >> 16);
+            const int tmax = seg_max[seg];
+            float4 n0 = cand[min(start, last)], n1 = cand[min(start + 1, last)];
+#pragma nounroll
+            for (int t = 0; t < tmax; t += 2) {
+                const float4 a0 = n0, a1 = n1;
+                const uint32_t j0 = start + t, j1 = j0 + 1;
+                n0 = cand[min(j0 + 2, last)];
+                n1 = cand[min(j1 + 2, last)];
+                const uint32_t k0 = t < len ? PC_KEY(a0, j0) : KEY_EMPTY;
+                const uint32_t k1 = t + 1 < len ? PC_KEY(a1, j1) : KEY_EMPTY;
+                list_insert<KS>(L, k0);
+                list_insert<KS>(L, k1);
+            }
         }
 #undef PC_KEY
         if (!active) continue;
@@ -163,13 +238,14 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         double dmin = INFINITY;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            if (lo[a] > 0) {
+            const int nlo = max(qc[a] - 1, 0), nhi = min(qc[a] + 1, gp.dim[a] - 1);
+            if (nlo > 0) {
                 whole = false;
-                dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)lo[a] * gp.cell));
+                dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)nlo * gp.cell));
             }
-            if (hi[a] < gp.dim[a] - 1) {
+            if (nhi < gp.dim[a] - 1) {
                 whole = false;
-                dmin = fmin(dmin, (gp.o[a] + (double)(hi[a] + 1) * gp.cell) - qv[a]);
+                dmin = fmin(dmin, (gp.o[a] + (double)(nhi + 1) * gp.cell) - qv[a]);
             }
         }
         double bound = INFINITY;  // no unscanned point is closer than sqrt(bound)
@@ -177,19 +253,21 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             const double b = dmin - eps;
             bound = b > 0 ? b * b : 0.0;
         }
-        // no unlisted candidate of the block is closer than sqrt(T * (1 - 2^-20))
+        // no unlisted candidate of the scanned cells is closer than sqrt(T * (1 - 2^-20))
         if (L[KS - 1] != KEY_EMPTY)
             bound = fmin(bound, (double)__uint_as_float(L[KS - 1] & ~ORD_MASK) * (1.0 - 9.5367431640625e-07));
 
         double dd[KS];
         int32_t id[KS];
-        int nsafe = 0;
+        uint32_t od[KS];
+        int nsafe = 0, cnt = 0;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             dd[s] = INFINITY;
             id[s] = 0x7fffffff;
+            od[s] = L[s] & ORD_MASK;
             if (L[s] != KEY_EMPTY) {
-                const float4 c = cand[L[s] & ORD_MASK];
+                const float4 c = cand[od[s]];
                 const double dx = qxd - (double)c.x, dy = qyd - (double)c.y, dz = qzd - (double)c.z;
                 double d = dx * dx;
                 d += dy * dy;
@@ -199,6 +277,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
                     if (!(r2lim >= 0.0 && !(d < r2lim))) {
                         dd[s] = d;
                         id[s] = __float_as_int(c.w);
+                        cnt++;
                     }
                 }
             }
@@ -209,20 +288,32 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             if (p < A.flag_cap) A.flag_list[p] = (int32_t)spos;
             continue;
         }
-        // rank the accepted entries by (d2, original index); rank r < k goes to ordbuf[r][lane]
-        int cnt = 0;
+        // The list is already ordered by the truncated fp32 key, so the exact (d2, index) order
+        // differs from it by a few adjacent transpositions at most: bubble passes until no lane of
+        // the wave swaps (excluded entries carry d2 = +inf and sink to the end).
+#pragma nounroll
+        for (int pass = 0; pass < KS; pass++) {
+            bool swapped = false;
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            if (id[s] != 0x7fffffff) {
-                int rank = 0;
-#pragma unroll
-                for (int u = 0; u < KS; u++)
-                    rank += (dd[u] < dd[s] || (dd[u] == dd[s] && id[u] < id[s])) ? 1 : 0;
-                if (rank < k) ordbuf[rank * PC_WAVE + lane] = (uint16_t)(L[s] & ORD_MASK);
-                cnt++;
+            for (int s = 0; s + 1 < KS; s++) {
+                const double da = dd[s], db = dd[s + 1];
+                const int32_t ia = id[s], ib = id[s + 1];
+                const uint32_t oa = od[s], ob = od[s + 1];
+                const bool gt = da > db || (da == db && ia > ib);
+                dd[s] = gt ? db : da;
+                dd[s + 1] = gt ? da : db;
+                id[s] = gt ? ib : ia;
+                id[s + 1] = gt ? ia : ib;
+                od[s] = gt ? ob : oa;
+                od[s + 1] = gt ? oa : ob;
+                swapped |= gt;
             }
+            if (!__any(swapped)) break;
         }
         cnt = min(cnt, k);
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+            if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
         emit_result<MODE>(A, (int64_t)__float_as_int(q4.w), cnt,
                           [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
                               const float4 c = cand[ordbuf[s * PC_WAVE + lane]];
@@ -249,6 +340,7 @@ void launch_tile(int mode, unsigned nblocks, size_t lds, hipStream_t st, const S
         case M_NNDIST:
             hipLaunchKernelGGL((k_tile_scan<KS, M_NNDIST>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
             break;
+        case M_ALL: hipLaunchKernelGGL((k_tile_scan<KS, M_ALL>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
         default: break;
     }
 }
@@ -270,7 +362,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             int t2[3] = {tile[0], tile[1], tile[2]};
             t2[a]++;
             if (t2[a] > g->gp.dim[a]) continue;
-            if ((t2[1] + 2) * (t2[2] + 2) > MAX_ROWS) continue;
+            if ((t2[1] + 2) * (t2[2] + 2) > MAX_ROWS || t2[0] + 2 > MAX_NX) continue;
             if ((double)t2[0] * t2[1] * t2[2] * occ > 54.0) continue;
             tile[a] = t2[a];
             grew = true;
@@ -290,7 +382,13 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     A.flag_count = flags.as<uint32_t>();
     A.flag_list = reinterpret_cast<int32_t *>(flags.as<char>() + 256);
     PC_HIP(hipMemsetAsync(A.flag_count, 0, 256, st));
-    const size_t lds = sizeof(float4) * CAND_CAP + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
+    // LDS for the candidate block: 1.6 x the expected block population, at most CAND_CAP_MAX
+    const double expect = occ * (tile[0] + 2) * (tile[1] + 2) * (tile[2] + 2);
+    int cap = ((int)(expect * 1.6) + 127) / 128 * 128;
+    cap = std::min(CAND_CAP_MAX, std::max(256, cap));
+    A.cand_cap = cap;
+    const size_t lds = sizeof(float4) * (size_t)cap + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+                       sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
     switch (ks) {
         case 4: launch_tile<4>(mode, (unsigned)nt, lds, st, A); break;

@@ -191,6 +191,22 @@ class HipEngine:
                                     self._dt(d2), _ptr(cnt), self.stream()), "pc_knn")
         return idx.cpu().numpy(), d2.cpu().numpy(), cnt.cpu().numpy()
 
+    def knn_fused(self, pts, k, radius, cache, want_rows=True, want_avg=True, want_normals=True, prior=None):
+        """One search, all consumers: (idx, d2, cnt, avg, normals) as numpy (None where not asked)."""
+        g = self.grid(pts, cache, k)
+        n = len(pts)
+        idx = self.empty((n, k), torch.int32) if want_rows else None
+        d2 = self.empty((n, k), torch.float64) if want_rows else None
+        cnt = self.empty((n,), torch.int32) if want_rows else None
+        avg = self.empty((n,), torch.float64) if want_avg else None
+        nrm = self.empty((n, 3), torch.float64) if want_normals else None
+        dp = None if prior is None else self.upload(np.asarray(prior, dtype=np.float64))
+        self._check(self.lib.pc_knn_fused(self.ctx, g.h, 0, n, int(k), float(radius), _ptr(idx), _ptr(d2),
+                                          _lib.PC_F64, _ptr(cnt), _ptr(avg), _ptr(nrm), _ptr(dp), self.stream()),
+                    "pc_knn_fused")
+        f = lambda t: None if t is None else t.cpu().numpy()
+        return f(idx), f(d2), f(cnt), f(avg), f(nrm)
+
     def sor_avg_dev(self, pts, k, cache) -> torch.Tensor:
         key = ("sor_avg", k)
         avg = cache.get(key)

@@ -214,3 +214,23 @@ def test_determinism(hip):
     b = hip.knn(p, None, 16, -1.0, {})
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert np.array_equal(hip.normals(p, 16, -1.0, None, {}), hip.normals(p, 16, -1.0, None, {}))
+
+
+@pytest.mark.parametrize("name", ["uniform", "sphere", "lidar", "fp64"])
+def test_fused_equals_separate(hip, oracle, name):
+    p = CLOUDS[name]()
+    idx, d2, cnt, avg, nrm = hip.knn_fused(p, 16, -1.0, {})
+    ridx, rd2, rcnt = oracle.knn(p, None, 16)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+    np.testing.assert_allclose(avg, oracle.sor_avg(p, 16), rtol=1e-13)
+    assert np.abs(nrm - oracle.normals(p, 16)).max() < 1e-6
+
+
+def test_large_uniform_matches_oracle(hip, oracle):
+    """1 M uniform points, k = 16 (BASELINE config 2): the tile path and its exact re-run."""
+    p = D.uniform_cube(1_000_000, 2)
+    idx, d2, cnt, avg, nrm = hip.knn_fused(p, 16, -1.0, {})
+    g = oracle.Grid(p)
+    ridx, rd2, rcnt = g.knn_self(16)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+    np.testing.assert_allclose(avg, np.sqrt(rd2).sum(1) / 16.0, rtol=1e-13)
