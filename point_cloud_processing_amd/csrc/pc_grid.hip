@@ -468,6 +468,10 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         for (int a = 0; a < 3; a++) vol *= std::max(ext[a], emax * 1e-3);
         cell = (n > 0 && vol > 0) ? cbrt(vol * target / (double)n) : 1.0;
         if (!(cell > 0) || !std::isfinite(cell)) cell = 1.0;
+        if (const char *e = getenv("PC_AMD_CELL_SCALE")) {  // tuning knob: scales the automatic edge
+            const double f = atof(e);
+            if (f > 0.1 && f < 10.0) cell *= f;
+        }
     }
     for (;;) {  // dense table capped at 8n + 4096 cells
         double tot = 1.0;

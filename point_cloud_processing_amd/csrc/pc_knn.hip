@@ -162,7 +162,7 @@ int launch_scan(pc_ctx *ctx, const pc_grid *g, int qdtype, const ScanArgs &A0, h
     // exact scan below then runs over that list only (persistent blocks, no host round trip)
     bool tiled = false;
     PC_TRY(pc_launch_tile_scan(ctx, g, MODE, A, st, &tiled));
-    const unsigned nb = tiled ? 2048u : (unsigned)std::min<int64_t>((A.nq + PC_WAVE - 1) / PC_WAVE, 0x7fffffff);
+    const unsigned nb = tiled ? 512u : (unsigned)std::min<int64_t>((A.nq + PC_WAVE - 1) / PC_WAVE, 0x7fffffff);
     const size_t lds = MODE == M_COUNT ? 0 : (sizeof(double) + sizeof(int32_t)) * PC_WAVE * (size_t)A.k;
     const bool ext = A.queries != nullptr;
     if (g->dtype == PC_F32) {

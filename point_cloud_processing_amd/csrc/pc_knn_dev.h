@@ -27,14 +27,18 @@ struct ScanArgs {
     // optional explicit list of sorted positions to answer (the exact re-run of queries that
     // the tile kernel could not certify); *qcount entries of qlist
     const int32_t *qlist;
+    const float *qub;       // per listed query: an upper bound of its k-th squared distance (or +inf)
     const uint32_t *qcount;
     // tile kernel only
     int tile[3];            // tile edge in cells
     int ntile[3];           // tiles per axis
     int64_t s_end;          // self-query range end (sorted position)
     int cand_cap;           // candidates the LDS block holds
-    int32_t *flag_list;     // queries handed to the exact re-run
+    int32_t *flag_list;     // queries handed to the exact re-run (one wave per query)
+    float *flag_ub;
     uint32_t *flag_count;
+    int32_t *flag2_list;    // queries the wave-per-query re-run hands on to the per-lane scan
+    uint32_t *flag2_count;
     uint32_t flag_cap;
 };
 
@@ -318,3 +322,5 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
 // pc_knn_tile.hip: the tile-cooperative fast path (fp32 grids, self-queries, k <= 32).
 // Returns PC_OK after enqueueing; *handled = false when the configuration is not supported.
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled);
+// pc_knn_wave.hip: one wave per listed query (A.qlist / A.qub / A.qcount).
+int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A, hipStream_t st);

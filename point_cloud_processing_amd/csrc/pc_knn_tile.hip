@@ -158,7 +158,10 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         if (overfull) {
             if (active) {
                 const uint32_t p = atomicAdd(A.flag_count, 1u);
-                if (p < A.flag_cap) A.flag_list[p] = (int32_t)spos;
+                if (p < A.flag_cap) {
+                    A.flag_list[p] = (int32_t)spos;
+                    A.flag_ub[p] = INFINITY;
+                }
             }
             continue;
         }
@@ -260,7 +263,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         double dd[KS];
         int32_t id[KS];
         uint32_t od[KS];
-        int nsafe = 0, cnt = 0;
+        int nsafe = 0, cnt = 0, nvalid = 0;
+        double dmax = 0.0;  // farthest listed candidate: bounds the k-th distance when k are listed
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             dd[s] = INFINITY;
@@ -272,6 +276,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
                 double d = dx * dx;
                 d += dy * dy;
                 d += dz * dz;
+                nvalid++;
+                dmax = fmax(dmax, d);
                 if (d < bound) {
                     nsafe++;
                     if (!(r2lim >= 0.0 && !(d < r2lim))) {
@@ -285,7 +291,10 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         const bool ok = nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim);
         if (!ok) {
             const uint32_t p = atomicAdd(A.flag_count, 1u);
-            if (p < A.flag_cap) A.flag_list[p] = (int32_t)spos;
+            if (p < A.flag_cap) {
+                A.flag_list[p] = (int32_t)spos;
+                A.flag_ub[p] = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
+            }
             continue;
         }
         // The list is already ordered by the truncated fp32 key, so the exact (d2, index) order
@@ -377,10 +386,15 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     if (nt > 0x7fffffff) return PC_OK;
     A.s_end = A.s_begin + A.nq;
     A.flag_cap = (uint32_t)A.nq;
-    Scratch flags(ctx, sizeof(int32_t) * (size_t)A.nq + 256);
-    if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run list");
+    // [counts (256 B)] [list 1] [upper bounds 1] [list 2]; the block returns to the pool when this
+    // function ends, which is safe because everything that touches it is ordered on `st`
+    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256);
+    if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run lists");
     A.flag_count = flags.as<uint32_t>();
+    A.flag2_count = A.flag_count + 16;
     A.flag_list = reinterpret_cast<int32_t *>(flags.as<char>() + 256);
+    A.flag_ub = reinterpret_cast<float *>(A.flag_list + A.nq);
+    A.flag2_list = A.flag_list + 2 * A.nq;
     PC_HIP(hipMemsetAsync(A.flag_count, 0, 256, st));
     // LDS for the candidate block: 1.6 x the expected block population, at most CAND_CAP_MAX
     const double expect = occ * (tile[0] + 2) * (tile[1] + 2) * (tile[2] + 2);
@@ -398,9 +412,15 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         default: launch_tile<34>(mode, (unsigned)nt, lds, st, A); break;
     }
     PC_HIP(hipGetLastError());
-    // the exact re-run answers whatever the tile kernel appended (device-side count, no host sync)
+    // second stage: one wave per uncertified query (device-side count, no host round trip) ...
     A.qlist = A.flag_list;
+    A.qub = A.flag_ub;
     A.qcount = A.flag_count;
+    PC_TRY(pc_launch_wave_query(ctx, g, mode, A, st));
+    // ... and whatever that stage could not hold is left for the per-lane scan of the caller
+    A.qlist = A.flag2_list;
+    A.qub = nullptr;
+    A.qcount = A.flag2_count;
     *handled = true;
     return PC_OK;
 }
