@@ -89,6 +89,9 @@ int pc_grid_info(const pc_grid *grid, double info[6]);
 /* Sorted-position -> original-index map of the grid (n x int32, device memory owned by the
  * grid).  Sorted position s is the unit the *_range entry points shard over. */
 const int32_t *pc_grid_perm_dev(const pc_grid *grid);
+/* Copies the original indices of sorted positions [s_begin, s_end) into out_dev. */
+int pc_grid_perm_copy(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int32_t *out_dev,
+                      void *stream);
 
 /* ---- exact kNN -----------------------------------------------------------------------------
  * Replaces KDTreeFlann::SearchKNN / SearchHybrid as reached from the calls listed above.

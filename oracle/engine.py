@@ -46,3 +46,26 @@ class OracleEngine:
 
     def knn(self, pts, q, k, radius, cache):
         return O.knn(pts, q, k, None if radius < 0 else radius)
+
+    # sharded variants used by the multi-process tests: the oracle shards original indices
+    def sor_avg_shard(self, pts, k, cache, rank, world):
+        from point_cloud_processing_amd.distributed import shard_range
+
+        b, e = shard_range(len(pts), rank, world)
+        key = ("sor_avg", k)
+        if key not in cache:
+            cache[key] = O.sor_avg(pts, k)
+        return np.arange(b, e, dtype=np.int64), cache[key][b:e]
+
+    def normals_shard(self, pts, k, radius, cache, rank, world):
+        from point_cloud_processing_amd.distributed import shard_range
+
+        b, e = shard_range(len(pts), rank, world)
+        return np.arange(b, e, dtype=np.int64), O.normals(pts, k, radius)[b:e]
+
+    def knn_shard(self, pts, k, radius, cache, rank, world):
+        from point_cloud_processing_amd.distributed import shard_range
+
+        b, e = shard_range(len(pts), rank, world)
+        idx, d2, cnt = O.knn(pts, pts[b:e], k, None if radius < 0 else radius)
+        return np.arange(b, e, dtype=np.int64), idx, d2, cnt

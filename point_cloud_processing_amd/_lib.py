@@ -32,6 +32,7 @@ SYMBOLS = [
     ("pc_grid_destroy", None, [_vp, _vp]),
     ("pc_grid_info", _i32, [_vp, _pd]),
     ("pc_grid_perm_dev", _vp, [_vp]),
+    ("pc_grid_perm_copy", _i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     ("pc_knn", _i32, [_vp, _vp, _vp, _i32, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp]),
     ("pc_knn_range", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp]),
     ("pc_sor_avg", _i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),

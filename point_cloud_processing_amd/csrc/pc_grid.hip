@@ -570,6 +570,16 @@ int pc_grid_info(const pc_grid *g, double info[6]) {
 
 const int32_t *pc_grid_perm_dev(const pc_grid *g) { return g ? g->perm : nullptr; }
 
+int pc_grid_perm_copy(pc_ctx *ctx, const pc_grid *g, int64_t s_begin, int64_t s_end, int32_t *out_dev, void *stream) {
+    if (!ctx || !g || s_begin < 0 || s_end < s_begin || s_end > g->n || (s_end > s_begin && !out_dev))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_grid_perm_copy");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (s_end > s_begin)
+        PC_HIP(hipMemcpyAsync(out_dev, g->perm + s_begin, sizeof(int32_t) * (size_t)(s_end - s_begin),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PC_OK;
+}
+
 int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
                    void *stream) {
     if (!ctx || m < 0 || (m > 0 && (!src_dev || !idx_dev || !dst_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_gather_rows");

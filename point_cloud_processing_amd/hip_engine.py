@@ -245,6 +245,42 @@ class HipEngine:
                                            self.stream()), "pc_sor_select")
         return kept[: nk.value].cpu().numpy().astype(np.int64)
 
+    # -- sharded variants: rank r of W answers sorted positions [r*n/W, (r+1)*n/W) --------------------
+    def _owned(self, g: DeviceGrid, rank: int, world: int):
+        from .distributed import shard_range
+
+        b, e = shard_range(g.n, rank, world)
+        t = self.empty((max(e - b, 1),), torch.int32)
+        self._check(self.lib.pc_grid_perm_copy(self.ctx, g.h, b, e, _ptr(t), self.stream()), "pc_grid_perm_copy")
+        return b, e, t[: e - b].cpu().numpy().astype(np.int64)
+
+    def sor_avg_shard(self, pts, k, cache, rank, world):
+        g = self.grid(pts, cache, k)
+        b, e, owned = self._owned(g, rank, world)
+        avg = torch.full((len(pts),), -2.0, dtype=torch.float64, device=self.device)
+        self._check(self.lib.pc_sor_avg(self.ctx, g.h, b, e, int(k), _ptr(avg), self.stream()), "pc_sor_avg")
+        return owned, avg.cpu().numpy()[owned]
+
+    def normals_shard(self, pts, k, radius, cache, rank, world):
+        g = self.grid(pts, cache, k)
+        b, e, owned = self._owned(g, rank, world)
+        out = torch.zeros((len(pts), 3), dtype=torch.float64, device=self.device)
+        self._check(self.lib.pc_normals(self.ctx, g.h, b, e, int(k), float(radius), None, _ptr(out), self.stream()),
+                    "pc_normals")
+        return owned, out.cpu().numpy()[owned]
+
+    def knn_shard(self, pts, k, radius, cache, rank, world):
+        g = self.grid(pts, cache, k)
+        b, e, owned = self._owned(g, rank, world)
+        n = len(pts)
+        idx = torch.full((n, k), -1, dtype=torch.int32, device=self.device)
+        d2 = torch.full((n, k), float("inf"), dtype=torch.float64, device=self.device)
+        cnt = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.pc_knn_range(self.ctx, g.h, b, e, int(k), float(radius), _ptr(idx), _ptr(d2),
+                                          _lib.PC_F64, _ptr(cnt), self.stream()), "pc_knn_range")
+        o = torch.from_numpy(owned).to(self.device)
+        return owned, idx[o].cpu().numpy(), d2[o].cpu().numpy(), cnt[o].cpu().numpy()
+
     def normals(self, pts, k, radius, prior, cache):
         g = self.grid(pts, cache, k)
         n = len(pts)

@@ -234,3 +234,24 @@ def test_large_uniform_matches_oracle(hip, oracle):
     ridx, rd2, rcnt = g.knn_self(16)
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
     np.testing.assert_allclose(avg, np.sqrt(rd2).sum(1) / 16.0, rtol=1e-13)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_query_shards_cover_and_agree(hip, oracle, world):
+    """Each rank's slice of sorted positions, run one after the other on this GPU, reproduces the
+    single-GPU result exactly (what 2/4/8 ranks compute in parallel)."""
+    p = D.gaussian_clusters(30000, 77)
+    cache = {}
+    ravg = oracle.sor_avg(p, 16)
+    rn = oracle.normals(p, 16)
+    ridx, rd2, rcnt = oracle.knn(p, None, 16)
+    seen = np.zeros(len(p), dtype=int)
+    for r in range(world):
+        owned, avg = hip.sor_avg_shard(p, 16, cache, r, world)
+        np.testing.assert_allclose(avg, ravg[owned], rtol=1e-13)
+        o2, nrm = hip.normals_shard(p, 16, -1.0, cache, r, world)
+        assert np.array_equal(o2, owned) and np.abs(nrm - rn[owned]).max() < 1e-6
+        o3, idx, d2, cnt = hip.knn_shard(p, 16, -1.0, cache, r, world)
+        assert np.array_equal(idx, ridx[owned]) and np.array_equal(d2, rd2[owned]) and np.array_equal(cnt, rcnt[owned])
+        seen[owned] += 1
+    assert (seen == 1).all()
