@@ -89,6 +89,8 @@ struct pc_grid {
 // pc_sort.hip
 int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
                         int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp);
+int pc_radix_sort_pairs32(pc_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                          int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp);
 int pc_exclusive_scan_u32(pc_ctx *ctx, uint32_t *data, int64_t n, hipStream_t st);
 // flags (0/1 bytes) -> ascending indices of the set flags; *count on host (synchronises)
 int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_idx, int64_t *count, hipStream_t st);

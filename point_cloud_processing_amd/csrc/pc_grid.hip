@@ -136,12 +136,31 @@ __global__ __launch_bounds__(256) void k_bbox(const T *__restrict__ xyz, int64_t
     }
 }
 
-__global__ void k_bbox_final(const double *__restrict__ partial, int nb, double *__restrict__ out) {
-    int a = threadIdx.x;
-    if (a >= 6) return;
-    double v = partial[a];
-    for (int b = 1; b < nb; b++) v = a < 3 ? fmin(v, partial[(size_t)b * 6 + a]) : fmax(v, partial[(size_t)b * 6 + a]);
-    out[a] = v;
+__global__ __launch_bounds__(64) void k_bbox_final(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+    const int lane = threadIdx.x;
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = lane; b < nb; b += 64) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            mn[a] = fmin(mn[a], partial[(size_t)b * 6 + a]);
+            mx[a] = fmax(mx[a], partial[(size_t)b * 6 + 3 + a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fmin(mn[a], __shfl_down(mn[a], o, 64));
+            mx[a] = fmax(mx[a], __shfl_down(mx[a], o, 64));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            out[a] = mn[a];
+            out[3 + a] = mx[a];
+        }
+    }
 }
 
 struct Affine {
@@ -189,10 +208,48 @@ __global__ __launch_bounds__(256) void k_cell_keys(const T *__restrict__ xyz, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_cell_count(const uint64_t *__restrict__ keys, int64_t n,
-                                                     uint32_t *__restrict__ cnt) {
+// kNN grid keys as u32 (the dense table has fewer than 2^32 cells)
+template <typename T>
+__global__ __launch_bounds__(256) void k_cell_keys32(const T *__restrict__ xyz, int64_t n, GridParams gp,
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[keys[i]], 1u);
+    if (i >= n) return;
+    uint32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double t = floor(((double)xyz[3 * i + a] - gp.o[a]) * gp.s);
+        c[a] = !(t > 0.0) ? 0u : (t >= (double)gp.dim[a] ? (uint32_t)(gp.dim[a] - 1) : (uint32_t)t);
+    }
+    keys[i] = (c[2] * (uint32_t)gp.dim[1] + c[1]) * (uint32_t)gp.dim[0] + c[0];
+    vals[i] = (uint32_t)i;
+}
+
+// Per-cell counts from the SORTED keys: the first element of every run finds the run's end
+// (a short linear probe, then a binary search) and stores the length; no atomics.
+__global__ __launch_bounds__(256) void k_cell_runs(const uint32_t *__restrict__ keys, int64_t n,
+                                                    uint32_t *__restrict__ cnt) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys[i];
+    if (i > 0 && keys[i - 1] == key) return;
+    int64_t e = i + 1;
+    int probe = 0;
+    while (e < n && probe < 16 && keys[e] == key) {
+        e++;
+        probe++;
+    }
+    if (e < n && keys[e] == key) {  // long run: upper bound by binary search
+        int64_t lo = e, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] <= key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        e = lo;
+    }
+    cnt[key] = (uint32_t)(e - i);
 }
 
 template <typename T, typename REC>
@@ -481,7 +538,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             g->gp.dim[a] = (int32_t)d;
             tot *= d;
         }
-        if (tot <= 8.0 * (double)n + 4096.0) break;
+        if (tot <= std::min(8.0 * (double)n + 4096.0, 4.0e9)) break;  // u32 cell keys
         cell *= 1.25;
     }
     g->gp.cell = cell;
@@ -506,28 +563,26 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             break;
         }
         if (n == 0) break;
-        Scratch keys(ctx, sizeof(uint64_t) * (size_t)n), keys2(ctx, sizeof(uint64_t) * (size_t)n);
+        Scratch keys(ctx, sizeof(uint32_t) * (size_t)n), keys2(ctx, sizeof(uint32_t) * (size_t)n);
         Scratch vals(ctx, sizeof(uint32_t) * (size_t)n), vals2(ctx, sizeof(uint32_t) * (size_t)n);
         if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok()) {
             rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
             break;
         }
         if (dtype == PC_F32)
-            hipLaunchKernelGGL((k_cell_keys<float, false>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                               (const float *)xyz_dev, n, g->gp, keys.as<uint64_t>(), vals.as<uint32_t>(),
-                               (int32_t *)nullptr);
+            hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
         else
-            hipLaunchKernelGGL((k_cell_keys<double, false>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                               (const double *)xyz_dev, n, g->gp, keys.as<uint64_t>(), vals.as<uint32_t>(),
-                               (int32_t *)nullptr);
-        // cell_start = exclusive scan of the per-cell counts
-        hipLaunchKernelGGL(k_cell_count, dim3(blocks_for(n, 256)), dim3(256), 0, st, keys.as<uint64_t>(), n,
-                           g->cell_start);
-        rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
-        if (rc) break;
+            hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
         bool in_tmp = false;
-        rc = pc_radix_sort_pairs(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(), keys2.as<uint64_t>(),
-                                 vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
+        rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
+                                   vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
+        if (rc) break;
+        // cell_start = exclusive scan of the per-cell counts (run lengths of the sorted keys)
+        hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                           in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>(), n, g->cell_start);
+        rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
         if (rc) break;
         const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
         if (dtype == PC_F32)

@@ -10,7 +10,8 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;  // keys per block and pas
 constexpr int RADIX = 256;
 
 // ---- pass 1: per-block digit histogram ----------------------------------------------------------
-__global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n, int shift,
+template <typename K>
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const K *__restrict__ keys, int64_t n, int shift,
                                                               uint32_t *__restrict__ block_hist, int nblocks) {
     __shared__ uint32_t hist[RADIX];
     hist[threadIdx.x] = 0;
@@ -26,10 +27,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const uint64_t *__r
 }
 
 // ---- pass 3: stable scatter ---------------------------------------------------------------------
-__global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *__restrict__ keys,
+template <typename K>
+__global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const K *__restrict__ keys,
                                                                  const uint32_t *__restrict__ vals, int64_t n,
                                                                  int shift, const uint32_t *__restrict__ block_off,
-                                                                 int nblocks, uint64_t *__restrict__ keys_out,
+                                                                 int nblocks, K *__restrict__ keys_out,
                                                                  uint32_t *__restrict__ vals_out) {
     __shared__ uint32_t run[RADIX];       // next output slot of each digit for this block
     __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counts of the current round
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const uint64_t *
         int64_t i = base + (int64_t)r * SORT_THREADS + tid;
         bool valid = i < n;
         if (base + (int64_t)r * SORT_THREADS >= n) break;  // uniform: whole round is past the end
-        uint64_t key = valid ? keys[i] : 0;
+        K key = valid ? keys[i] : 0;
         uint32_t val = valid ? vals[i] : 0;
         uint32_t d = (uint32_t)(key >> shift) & (RADIX - 1);
         // lanes of this wave holding the same digit
@@ -211,8 +213,9 @@ int pc_exclusive_scan_u32(pc_ctx *ctx, uint32_t *data, int64_t n, hipStream_t st
     return PC_OK;
 }
 
-int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
-                        int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp) {
+template <typename K>
+static int radix_sort_impl(pc_ctx *ctx, K *keys, uint32_t *vals, K *keys_tmp, uint32_t *vals_tmp, int64_t n,
+                           int key_bits, hipStream_t st, bool *result_in_tmp) {
     *result_in_tmp = false;
     if (n <= 1) return PC_OK;
     if (key_bits < 1) key_bits = 1;
@@ -220,16 +223,16 @@ int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *k
     int nblocks = (int)((n + SORT_TILE - 1) / SORT_TILE);
     Scratch hist(ctx, sizeof(uint32_t) * (size_t)RADIX * (size_t)nblocks);
     if (!hist.ok()) return pc_fail(ctx, PC_NOMEM, "radix histogram");
-    uint64_t *kin = keys, *kout = keys_tmp;
+    K *kin = keys, *kout = keys_tmp;
     uint32_t *vin = vals, *vout = vals_tmp;
     for (int p = 0; p < passes; p++) {
         int shift = 8 * p;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, n, shift,
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, n, shift,
                            hist.as<uint32_t>(), nblocks);
         PC_TRY(pc_exclusive_scan_u32(ctx, hist.as<uint32_t>(), (int64_t)RADIX * nblocks, st));
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, vin, n, shift,
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nblocks), dim3(SORT_THREADS), 0, st, kin, vin, n, shift,
                            hist.as<uint32_t>(), nblocks, kout, vout);
-        uint64_t *tk = kin;
+        K *tk = kin;
         kin = kout;
         kout = tk;
         uint32_t *tv = vin;
@@ -239,6 +242,16 @@ int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *k
     PC_HIP(hipGetLastError());
     *result_in_tmp = (kin != keys);
     return PC_OK;
+}
+
+int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
+                        int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp) {
+    return radix_sort_impl<uint64_t>(ctx, keys, vals, keys_tmp, vals_tmp, n, key_bits, st, result_in_tmp);
+}
+
+int pc_radix_sort_pairs32(pc_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                          int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp) {
+    return radix_sort_impl<uint32_t>(ctx, keys, vals, keys_tmp, vals_tmp, n, key_bits, st, result_in_tmp);
 }
 
 int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_idx, int64_t *count,
