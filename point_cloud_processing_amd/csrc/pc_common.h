@@ -21,6 +21,7 @@ struct pc_ctx {
     };
     std::vector<Block> pool;
     size_t pool_bytes = 0;
+    void *pinned = nullptr;  // 4 KiB of page-locked host memory for small device-to-host readbacks
 
     void *alloc(size_t bytes);
     void release(void *p);
@@ -84,6 +85,10 @@ struct pc_grid {
     int32_t *perm = nullptr;      // sorted position -> original index
     int64_t ncell = 0;
     size_t bytes = 0;
+    int64_t occupied = 0;     // number of non-empty cells (0: not measured)
+    // tile shape of the cooperative kNN kernel, chosen on first use (0: not chosen yet)
+    mutable int tile[3] = {0, 0, 0};
+    mutable int tile_cap = 0;
 };
 
 // pc_sort.hip

@@ -83,6 +83,10 @@ int pc_create(int device, pc_ctx **out) {
     pc_ctx *c = new (std::nothrow) pc_ctx();
     if (!c) return PC_NOMEM;
     c->device = device;
+    if (hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return PC_NOMEM;
+    }
     *out = c;
     return PC_OK;
 }
@@ -91,6 +95,7 @@ void pc_destroy(pc_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->pool) (void)hipFree(b.p);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 
@@ -252,6 +257,53 @@ __global__ __launch_bounds__(256) void k_cell_runs(const uint32_t *__restrict__ 
     cnt[key] = (uint32_t)(e - i);
 }
 
+// Occupancy statistics of the sorted keys: stats[0] += sum over runs of len^2 (n times the
+// occupancy a random point sees), stats[1] += number of runs (occupied cells).
+__global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ keys, int64_t n,
+                                                    unsigned long long *__restrict__ stats) {
+    unsigned long long sq = 0, runs = 0;
+    // grid-stride: a few thousand atomics in total instead of one pair per wave
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t key = keys[i];
+        if (i == 0 || keys[i - 1] != key) {
+            int64_t e = i + 1;
+            int probe = 0;
+            while (e < n && probe < 16 && keys[e] == key) {
+                e++;
+                probe++;
+            }
+            if (e < n && keys[e] == key) {
+                int64_t lo = e, hi = n;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (keys[mid] <= key)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                e = lo;
+            }
+            sq += (unsigned long long)(e - i) * (unsigned long long)(e - i);
+            runs += 1;
+        }
+    }
+    __shared__ unsigned long long red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sq += __shfl_down(sq, o, 64);
+        runs += __shfl_down(runs, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sq;
+        red[1][threadIdx.x >> 6] = runs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&stats[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
 template <typename T, typename REC>
 __global__ __launch_bounds__(256) void k_gather_records(const T *__restrict__ xyz, const uint32_t *__restrict__ vals,
                                                          int64_t n, REC *__restrict__ rec,
@@ -354,8 +406,8 @@ int bbox_impl(pc_ctx *ctx, const void *xyz, int dtype, int64_t n, double mn[3], 
         hipLaunchKernelGGL(k_bbox<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz, n, p);
     hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(64), 0, st, p, nb, p + (size_t)nb * 6);
     PC_HIP(hipGetLastError());
-    double h[6];
-    PC_HIP(hipMemcpyAsync(h, p + (size_t)nb * 6, sizeof(h), hipMemcpyDeviceToHost, st));
+    double *h = reinterpret_cast<double *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(h, p + (size_t)nb * 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));
     for (int a = 0; a < 3; a++) {
         mn[a] = h[a];
@@ -514,13 +566,14 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         emax = std::max(emax, ext[a]);
         g->gp.o[a] = mn[a];
     }
-    double cell = cell_size;
-    if (!(cell > 0)) {
+    const bool automatic = !(cell_size > 0);
+    double cell = cell_size, target = 1.0;
+    if (automatic) {
         // cell edge ~ the 99.5 % quantile of the k-th neighbour distance in a uniform cloud
         // (the ball then holds k + 2.6 sqrt(k) + 1 points): one ring of cells around a query's
         // cell certifies almost every query
         const double kk = (double)std::max(1, k_hint);
-        double target = std::max(1.0, 0.2387 * (kk + 2.6 * sqrt(kk) + 1.0));
+        target = std::max(1.0, 0.2387 * (kk + 2.6 * sqrt(kk) + 1.0));
         double vol = 1.0;
         for (int a = 0; a < 3; a++) vol *= std::max(ext[a], emax * 1e-3);
         cell = (n > 0 && vol > 0) ? cbrt(vol * target / (double)n) : 1.0;
@@ -530,55 +583,89 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             if (f > 0.1 && f < 10.0) cell *= f;
         }
     }
-    for (;;) {  // dense table capped at 8n + 4096 cells
-        double tot = 1.0;
-        for (int a = 0; a < 3; a++) {
-            double d = floor(ext[a] / cell) + 1.0;
-            d = std::min(d, 2.0e9);
-            g->gp.dim[a] = (int32_t)d;
-            tot *= d;
+    // dense cell table, capped at 16 n + 4096 cells (and below 2^32: u32 cell keys)
+    auto fit_dims = [&](double c, int32_t dim[3]) {
+        for (;;) {
+            double tot = 1.0;
+            for (int a = 0; a < 3; a++) {
+                double d = std::min(floor(ext[a] / c) + 1.0, 2.0e9);
+                dim[a] = (int32_t)d;
+                tot *= d;
+            }
+            if (tot <= std::min(16.0 * (double)n + 4096.0, 4.0e9)) return c;
+            c *= 1.1;
         }
-        if (tot <= std::min(8.0 * (double)n + 4096.0, 4.0e9)) break;  // u32 cell keys
-        cell *= 1.25;
-    }
-    g->gp.cell = cell;
-    g->gp.s = 1.0 / cell;
-    g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
+    };
+    cell = fit_dims(cell, g->gp.dim);
 
     size_t rec_bytes = (dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64)) * (size_t)std::max<int64_t>(n, 1);
-    size_t cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
     size_t perm_bytes = sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1);
-    g->rec = ctx->alloc(rec_bytes);
-    g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
-    g->perm = (int32_t *)ctx->alloc(perm_bytes);
-    g->bytes = rec_bytes + cs_bytes + perm_bytes;
-    if (!g->rec || !g->cell_start || !g->perm) {
-        pc_grid_destroy(ctx, g);
-        return pc_fail(ctx, PC_NOMEM, "grid buffers");
-    }
+    size_t cs_bytes = 0;
     rc = PC_OK;
     do {
+        Scratch keys(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)),
+            keys2(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1));
+        Scratch vals(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)),
+            vals2(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1));
+        Scratch stats(ctx, 256);
+        if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok() || !stats.ok()) {
+            rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
+            break;
+        }
+        bool in_tmp = false;
+        // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
+        // far more points than intended (surfaces and clusters fill few cells of the box densely).
+        for (int attempt = 0; n > 0; attempt++) {
+            g->gp.cell = cell;
+            g->gp.s = 1.0 / cell;
+            g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
+            if (dtype == PC_F32)
+                hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                   (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                   (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+            rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
+                                       vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
+            if (rc || !automatic || attempt >= 5) break;
+            unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
+            if (hipMemsetAsync(stats.p, 0, 16, st) != hipSuccess) break;
+            hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st,
+                               in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>(), n,
+                               stats.as<unsigned long long>());
+            if (hipMemcpyAsync(hs, stats.p, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) {
+                rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
+                break;
+            }
+            const double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
+            g->occupied = (int64_t)hs[1];
+            if (seen <= 2.0 * (target + 1.0)) break;
+            int32_t dim2[3];
+            const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
+            const double got = fit_dims(want, dim2);
+            if (got > 0.93 * cell) break;  // the table cap binds: no finer grid available
+            cell = got;
+            for (int a = 0; a < 3; a++) g->gp.dim[a] = dim2[a];
+        }
+        if (rc) break;
+        g->gp.cell = cell;
+        g->gp.s = 1.0 / cell;
+        g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
+        cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
+        g->rec = ctx->alloc(rec_bytes);
+        g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
+        g->perm = (int32_t *)ctx->alloc(perm_bytes);
+        g->bytes = rec_bytes + cs_bytes + perm_bytes;
+        if (!g->rec || !g->cell_start || !g->perm) {
+            rc = pc_fail(ctx, PC_NOMEM, "grid buffers");
+            break;
+        }
         if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
             rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
             break;
         }
         if (n == 0) break;
-        Scratch keys(ctx, sizeof(uint32_t) * (size_t)n), keys2(ctx, sizeof(uint32_t) * (size_t)n);
-        Scratch vals(ctx, sizeof(uint32_t) * (size_t)n), vals2(ctx, sizeof(uint32_t) * (size_t)n);
-        if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok()) {
-            rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
-            break;
-        }
-        if (dtype == PC_F32)
-            hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                               (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
-        else
-            hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                               (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
-        bool in_tmp = false;
-        rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
-                                   vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
-        if (rc) break;
         // cell_start = exclusive scan of the per-cell counts (run lengths of the sorted keys)
         hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st,
                            in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>(), n, g->cell_start);

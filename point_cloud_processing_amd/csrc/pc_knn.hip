@@ -257,8 +257,11 @@ int sor_reduce(pc_ctx *ctx, int what, const double *avg, int64_t n, double mean,
         hipLaunchKernelGGL(k_sor_reduce<1>, dim3(RED_BLOCKS), dim3(256), 0, st, avg, n, mean, p);
     hipLaunchKernelGGL(k_sor_reduce_final, dim3(1), dim3(64), 0, st, p, RED_BLOCKS, p + 2 * RED_BLOCKS);
     PC_HIP(hipGetLastError());
-    PC_HIP(hipMemcpyAsync(out, p + 2 * RED_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    double *hp = reinterpret_cast<double *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(hp, p + 2 * RED_BLOCKS, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));
+    out[0] = hp[0];
+    out[1] = hp[1];
     return PC_OK;
 }
 

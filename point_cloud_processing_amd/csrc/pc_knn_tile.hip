@@ -1,4 +1,4 @@
-// Tile-cooperative exact kNN for fp32 grids (self-queries, k <= 32).
+// Tile-cooperative exact kNN (self-queries, k <= 32; fp32 and fp64 grids).
 //
 // One wave owns one tile of cells.  The tile's candidate block (the tile plus a one-cell halo;
 // its (y,z) rows are contiguous point ranges) is staged once into LDS; each lane then answers
@@ -39,7 +39,44 @@ __device__ inline void list_insert(uint32_t (&L)[KS], uint32_t key) {
     L[0] = min(L[0], key);
 }
 
-template <int KS, int MODE>
+// How the two record types appear in the LDS candidate block.
+//  fp32 grids: the record itself {x, y, z, original index}: fp32 differences of the stored values
+//              carry only a relative rounding error.
+//  fp64 grids: {x, y, z relative to the block origin, rounded to fp32; sorted position}: the filter
+//              works on rounded coordinates, so its keys carry an ABSOLUTE error of at most
+//              ~2^-21 * block extent on the distance, which the certification bound subtracts; the
+//              exact finish re-reads the fp64 record by its sorted position.
+template <typename REC>
+struct TileRec;
+template <>
+struct TileRec<Rec32> {
+    static constexpr bool kRelative = false;
+    __device__ static inline float4 stage(const Rec32 *rec, uint32_t src, const double *) {
+        return *reinterpret_cast<const float4 *>(rec + src);
+    }
+    __device__ static inline void exact(const Rec32 *, const float4 &c, double &x, double &y, double &z, int32_t &id) {
+        x = (double)c.x;
+        y = (double)c.y;
+        z = (double)c.z;
+        id = __float_as_int(c.w);
+    }
+};
+template <>
+struct TileRec<Rec64> {
+    static constexpr bool kRelative = true;
+    __device__ static inline float4 stage(const Rec64 *rec, uint32_t src, const double *org) {
+        double x, y, z;
+        int32_t id;
+        RecTraits<Rec64>::load(rec + src, x, y, z, id);
+        return make_float4((float)(x - org[0]), (float)(y - org[1]), (float)(z - org[2]), __uint_as_float(src));
+    }
+    __device__ static inline void exact(const Rec64 *rec, const float4 &c, double &x, double &y, double &z,
+                                        int32_t &id) {
+        RecTraits<Rec64>::load(rec + __float_as_uint(c.w), x, y, z, id);
+    }
+};
+
+template <typename REC, int KS, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *cand = reinterpret_cast<float4 *>(smem);                                               // [cand_cap]
@@ -49,7 +86,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     uint16_t *ordbuf = cell_off + MAX_ROWS * (MAX_NX + 1);                                         // [k][64]
     const int lane = threadIdx.x;
     const GridParams &gp = A.gp;
-    const Rec32 *rec = reinterpret_cast<const Rec32 *>(A.rec);
+    const REC *rec = reinterpret_cast<const REC *>(A.rec);
     const int k = A.k;
 
     // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
@@ -68,6 +105,10 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     }
     const int nry = hi[1] - lo[1] + 1, nrz = hi[2] - lo[2] + 1;
     const int nrows = nry * nrz;  // <= MAX_ROWS by construction of the tile shape
+    // block origin and extent (world units): the frame of the fp32 filter of fp64 grids
+    const double org[3] = {gp.o[0] + (double)lo[0] * gp.cell, gp.o[1] + (double)lo[1] * gp.cell,
+                           gp.o[2] + (double)lo[2] * gp.cell};
+    const double bext = gp.cell * (double)max(max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) + gp.cell;
 
     // ---- row table: lane r describes block row r -------------------------------------------------
     uint32_t row_begin = 0, row_cnt = 0, q_begin = 0, q_cnt = 0;
@@ -125,7 +166,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             }
             float4 v[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) v[b] = *reinterpret_cast<const float4 *>(rec + src[b]);
+            for (int b = 0; b < 4; b++) v[b] = TileRec<REC>::stage(rec, src[b], org);
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const uint32_t i = base + b * PC_WAVE + lane;
@@ -165,9 +206,13 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             }
             continue;
         }
-        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) q4 = *reinterpret_cast<const float4 *>(rec + spos);
-        const float qx = q4.x, qy = q4.y, qz = q4.z;
+        double qxd = 0.0, qyd = 0.0, qzd = 0.0;
+        int32_t qid = 0;
+        if (active) RecTraits<REC>::load(rec + spos, qxd, qyd, qzd, qid);
+        // filter coordinates: the stored fp32 values, or fp32 offsets from the block origin
+        const float qx = TileRec<REC>::kRelative ? (float)(qxd - org[0]) : (float)qxd;
+        const float qy = TileRec<REC>::kRelative ? (float)(qyd - org[1]) : (float)qyd;
+        const float qz = TileRec<REC>::kRelative ? (float)(qzd - org[2]) : (float)qzd;
 
         uint32_t L[KS];
 #pragma unroll
@@ -178,10 +223,10 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         // segments are visited in lock-step, each for the longest segment any lane has.
         int qc[3];
         {
-            const float qf[3] = {qx, qy, qz};
+            const double qf[3] = {qxd, qyd, qzd};
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                const double tt = floor(((double)qf[a] - gp.o[a]) * gp.s);
+                const double tt = floor((qf[a] - gp.o[a]) * gp.s);
                 qc[a] = !(tt > 0.0) ? 0 : (tt >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)tt);
             }
         }
@@ -235,7 +280,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         if (!active) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
-        const double qxd = (double)qx, qyd = (double)qy, qzd = (double)qz;
         const double qv[3] = {qxd, qyd, qzd};
         bool whole = true;
         double dmin = INFINITY;
@@ -257,8 +301,16 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             bound = b > 0 ? b * b : 0.0;
         }
         // no unlisted candidate of the scanned cells is closer than sqrt(T * (1 - 2^-20))
-        if (L[KS - 1] != KEY_EMPTY)
-            bound = fmin(bound, (double)__uint_as_float(L[KS - 1] & ~ORD_MASK) * (1.0 - 9.5367431640625e-07));
+        if (L[KS - 1] != KEY_EMPTY) {
+            const double T = (double)__uint_as_float(L[KS - 1] & ~ORD_MASK);
+            if (TileRec<REC>::kRelative) {
+                // keys were measured on coordinates rounded in the block frame
+                const double rt = sqrt(T) * (1.0 - 9.5367431640625e-07) - 4.76837158203125e-07 * bext;
+                bound = fmin(bound, rt > 0.0 ? rt * rt : 0.0);
+            } else {
+                bound = fmin(bound, T * (1.0 - 9.5367431640625e-07));
+            }
+        }
 
         double dd[KS];
         int32_t id[KS];
@@ -271,8 +323,10 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             id[s] = 0x7fffffff;
             od[s] = L[s] & ORD_MASK;
             if (L[s] != KEY_EMPTY) {
-                const float4 c = cand[od[s]];
-                const double dx = qxd - (double)c.x, dy = qyd - (double)c.y, dz = qzd - (double)c.z;
+                double cx, cy, cz;
+                int32_t cid;
+                TileRec<REC>::exact(rec, cand[od[s]], cx, cy, cz, cid);
+                const double dx = qxd - cx, dy = qyd - cy, dz = qzd - cz;
                 double d = dx * dx;
                 d += dy * dy;
                 d += dz * dz;
@@ -282,7 +336,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
                     nsafe++;
                     if (!(r2lim >= 0.0 && !(d < r2lim))) {
                         dd[s] = d;
-                        id[s] = __float_as_int(c.w);
+                        id[s] = cid;
                         cnt++;
                     }
                 }
@@ -323,34 +377,149 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
 #pragma unroll
         for (int s = 0; s < KS; s++)
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
-        emit_result<MODE>(A, (int64_t)__float_as_int(q4.w), cnt,
+        emit_result<MODE>(A, (int64_t)qid, cnt,
                           [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
-                              const float4 c = cand[ordbuf[s * PC_WAVE + lane]];
-                              x = (double)c.x;
-                              y = (double)c.y;
-                              z = (double)c.z;
+                              TileRec<REC>::exact(rec, cand[ordbuf[s * PC_WAVE + lane]], x, y, z, nid);
                               const double dx = qxd - x, dy = qyd - y, dz = qzd - z;
                               d = dx * dx;
                               d += dy * dy;
                               d += dz * dz;
-                              nid = __float_as_int(c.w);
                           });
     }
 }
 
-template <int KS>
+// ---- tile shape probe ------------------------------------------------------------------------------
+// The best tile shape depends on how the cloud fills space (a surface crosses ~t^2 of a t^3 tile's
+// cells, a volume fills all of them).  Sample points, and for every candidate shape measure the
+// population of the tile and of the tile+halo block the point lives in.  Per shape:
+//   acc[0] = sum of lane efficiency  pop / (64 * ceil(pop / 64))   (0 when the block overflows LDS)
+//   acc[1] = sum of block population, acc[2] = sum of its square.
+constexpr int NSHAPE = 12;
+__constant__ int c_shapes[NSHAPE][3] = {{1, 1, 1}, {2, 1, 1}, {2, 2, 1}, {2, 2, 2}, {3, 2, 2}, {3, 3, 2},
+                                        {3, 3, 3}, {4, 3, 3}, {4, 4, 3}, {4, 4, 4}, {5, 5, 4}, {5, 6, 6}};
+const int h_shapes[NSHAPE][3] = {{1, 1, 1}, {2, 1, 1}, {2, 2, 1}, {2, 2, 2}, {3, 2, 2}, {3, 3, 2},
+                                 {3, 3, 3}, {4, 3, 3}, {4, 4, 3}, {4, 4, 4}, {5, 5, 4}, {5, 6, 6}};
+
+template <typename REC>
+__global__ __launch_bounds__(256) void k_tile_probe(GridParams gp, const REC *__restrict__ rec,
+                                                     const uint32_t *__restrict__ cell_start, int64_t n,
+                                                     int64_t stride, int nsample, float *__restrict__ acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nsample) return;
+    const int64_t s = min((int64_t)i * stride, n - 1);
+    double qf[3];
+    int32_t qid;
+    RecTraits<REC>::load(rec + s, qf[0], qf[1], qf[2], qid);
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double t = floor((qf[a] - gp.o[a]) * gp.s);
+        c[a] = !(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)t);
+    }
+    for (int sh = 0; sh < NSHAPE; sh++) {
+        int t0[3], t1[3], lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            t0[a] = (c[a] / c_shapes[sh][a]) * c_shapes[sh][a];
+            t1[a] = min(t0[a] + c_shapes[sh][a], gp.dim[a]) - 1;
+            lo[a] = max(t0[a] - 1, 0);
+            hi[a] = min(t1[a] + 1, gp.dim[a] - 1);
+        }
+        uint32_t pop = 0, blk = 0;
+        for (int z = lo[2]; z <= hi[2]; z++)
+            for (int y = lo[1]; y <= hi[1]; y++) {
+                const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+                blk += cell_start[row + hi[0] + 1] - cell_start[row + lo[0]];
+                if (z >= t0[2] && z <= t1[2] && y >= t0[1] && y <= t1[1])
+                    pop += cell_start[row + t1[0] + 1] - cell_start[row + t0[0]];
+            }
+        const float eff = blk > (uint32_t)CAND_CAP_MAX ? 0.f : (float)pop / (64.f * (float)((pop + 63) / 64));
+        atomicAdd(&acc[sh * 4 + 0], eff);
+        atomicAdd(&acc[sh * 4 + 1], (float)blk);
+        atomicAdd(&acc[sh * 4 + 2], (float)blk * (float)blk);
+    }
+}
+
+// chooses g->tile / g->tile_cap (once per grid)
+int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
+    if (g->tile[0] > 0) return PC_OK;
+    const double occ = (double)g->n / (double)std::max<int64_t>(1, g->ncell);
+    const bool dense = g->occupied == 0 || (double)g->occupied > 0.85 * (double)g->ncell;
+    int best[3] = {1, 1, 1};
+    double expect;
+    if (dense) {
+        // the cloud fills its box: grow z, y, x in turn while the expected population fits a wave
+        const int order[3] = {2, 1, 0};
+        for (bool grew = true; grew;) {
+            grew = false;
+            for (int oi = 0; oi < 3; oi++) {
+                const int a = order[oi];
+                int t2[3] = {best[0], best[1], best[2]};
+                t2[a]++;
+                if (t2[a] > g->gp.dim[a]) continue;
+                if ((t2[1] + 2) * (t2[2] + 2) > MAX_ROWS || t2[0] + 2 > MAX_NX) continue;
+                if ((double)t2[0] * t2[1] * t2[2] * occ > 54.0) continue;
+                best[a] = t2[a];
+                grew = true;
+            }
+        }
+        expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2) * 1.6;
+    } else {
+        const int nsample = (int)std::min<int64_t>(8192, g->n);
+        Scratch acc(ctx, sizeof(float) * 4 * NSHAPE);
+        if (!acc.ok()) return pc_fail(ctx, PC_NOMEM, "tile probe");
+        PC_HIP(hipMemsetAsync(acc.p, 0, sizeof(float) * 4 * NSHAPE, st));
+        if (g->dtype == PC_F32)
+            hipLaunchKernelGGL(k_tile_probe<Rec32>, dim3((nsample + 255) / 256), dim3(256), 0, st, g->gp,
+                               (const Rec32 *)g->rec, g->cell_start, g->n, std::max<int64_t>(1, g->n / nsample), nsample,
+                               acc.as<float>());
+        else
+            hipLaunchKernelGGL(k_tile_probe<Rec64>, dim3((nsample + 255) / 256), dim3(256), 0, st, g->gp,
+                               (const Rec64 *)g->rec, g->cell_start, g->n, std::max<int64_t>(1, g->n / nsample), nsample,
+                               acc.as<float>());
+        float *h = reinterpret_cast<float *>(ctx->pinned);
+        PC_HIP(hipMemcpyAsync(h, acc.p, sizeof(float) * 4 * NSHAPE, hipMemcpyDeviceToHost, st));
+        PC_HIP(hipStreamSynchronize(st));
+        int bi = 0;
+        for (int sh = 1; sh < NSHAPE; sh++) {
+            bool fits = true;
+            for (int a = 0; a < 3; a++) fits = fits && h_shapes[sh][a] <= std::max(1, (int)g->gp.dim[a]);
+            if (fits && h[sh * 4] > h[bi * 4] * 1.02f) bi = sh;
+        }
+        for (int a = 0; a < 3; a++) best[a] = h_shapes[bi][a];
+        const double mean = h[bi * 4 + 1] / nsample, var = std::max(0.0, h[bi * 4 + 2] / nsample - mean * mean);
+        expect = mean + 2.5 * sqrt(var);
+    }
+    int cap = ((int)expect + 127) / 128 * 128;
+    g->tile_cap = std::min(CAND_CAP_MAX, std::max(256, cap));
+    for (int a = 0; a < 3; a++) g->tile[a] = best[a];
+    return PC_OK;
+}
+
+template <typename REC, int KS>
 void launch_tile(int mode, unsigned nblocks, size_t lds, hipStream_t st, const ScanArgs &A) {
     switch (mode) {
-        case M_KNN: hipLaunchKernelGGL((k_tile_scan<KS, M_KNN>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
-        case M_SOR: hipLaunchKernelGGL((k_tile_scan<KS, M_SOR>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
+        case M_KNN: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_KNN>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
+        case M_SOR: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_SOR>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
         case M_NORMALS:
-            hipLaunchKernelGGL((k_tile_scan<KS, M_NORMALS>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
+            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NORMALS>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
             break;
         case M_NNDIST:
-            hipLaunchKernelGGL((k_tile_scan<KS, M_NNDIST>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
+            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NNDIST>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
             break;
-        case M_ALL: hipLaunchKernelGGL((k_tile_scan<KS, M_ALL>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
+        case M_ALL: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_ALL>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
         default: break;
+    }
+}
+
+template <typename REC>
+void launch_tile_ks(int ks, int mode, unsigned nblocks, size_t lds, hipStream_t st, const ScanArgs &A) {
+    switch (ks) {
+        case 4: launch_tile<REC, 4>(mode, nblocks, lds, st, A); break;
+        case 10: launch_tile<REC, 10>(mode, nblocks, lds, st, A); break;
+        case 18: launch_tile<REC, 18>(mode, nblocks, lds, st, A); break;
+        case 22: launch_tile<REC, 22>(mode, nblocks, lds, st, A); break;
+        default: launch_tile<REC, 34>(mode, nblocks, lds, st, A); break;
     }
 }
 
@@ -358,25 +527,10 @@ void launch_tile(int mode, unsigned nblocks, size_t lds, hipStream_t st, const S
 
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled) {
     *handled = false;
-    if (g->dtype != PC_F32 || A.queries != nullptr || A.k > 32 || mode == M_COUNT || A.nq <= 0) return PC_OK;
+    if (A.queries != nullptr || A.k > 32 || mode == M_COUNT || A.nq <= 0) return PC_OK;
     if (getenv("PC_AMD_EXACT_SCAN_ONLY")) return PC_OK;  // A/B switch: one-query-per-lane fp64 scan only
-    // tile shape: grow z, y, x in turn while the expected tile population stays within one wave
-    const double occ = (double)g->n / (double)std::max<int64_t>(1, g->ncell);
-    int tile[3] = {1, 1, 1};
-    const int order[3] = {2, 1, 0};
-    for (bool grew = true; grew;) {
-        grew = false;
-        for (int oi = 0; oi < 3; oi++) {
-            const int a = order[oi];
-            int t2[3] = {tile[0], tile[1], tile[2]};
-            t2[a]++;
-            if (t2[a] > g->gp.dim[a]) continue;
-            if ((t2[1] + 2) * (t2[2] + 2) > MAX_ROWS || t2[0] + 2 > MAX_NX) continue;
-            if ((double)t2[0] * t2[1] * t2[2] * occ > 54.0) continue;
-            tile[a] = t2[a];
-            grew = true;
-        }
-    }
+    PC_TRY(choose_tile(ctx, g, st));
+    const int *tile = g->tile;
     int64_t nt = 1;
     for (int a = 0; a < 3; a++) {
         A.tile[a] = tile[a];
@@ -396,21 +550,15 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     A.flag_ub = reinterpret_cast<float *>(A.flag_list + A.nq);
     A.flag2_list = A.flag_list + 2 * A.nq;
     PC_HIP(hipMemsetAsync(A.flag_count, 0, 256, st));
-    // LDS for the candidate block: 1.6 x the expected block population, at most CAND_CAP_MAX
-    const double expect = occ * (tile[0] + 2) * (tile[1] + 2) * (tile[2] + 2);
-    int cap = ((int)(expect * 1.6) + 127) / 128 * 128;
-    cap = std::min(CAND_CAP_MAX, std::max(256, cap));
+    const int cap = g->tile_cap;
     A.cand_cap = cap;
     const size_t lds = sizeof(float4) * (size_t)cap + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
                        sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
-    switch (ks) {
-        case 4: launch_tile<4>(mode, (unsigned)nt, lds, st, A); break;
-        case 10: launch_tile<10>(mode, (unsigned)nt, lds, st, A); break;
-        case 18: launch_tile<18>(mode, (unsigned)nt, lds, st, A); break;
-        case 22: launch_tile<22>(mode, (unsigned)nt, lds, st, A); break;
-        default: launch_tile<34>(mode, (unsigned)nt, lds, st, A); break;
-    }
+    if (g->dtype == PC_F32)
+        launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, lds, st, A);
+    else
+        launch_tile_ks<Rec64>(ks, mode, (unsigned)nt, lds, st, A);
     PC_HIP(hipGetLastError());
     // second stage: one wave per uncertified query (device-side count, no host round trip) ...
     A.qlist = A.flag_list;

@@ -267,9 +267,9 @@ int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_
     PC_TRY(pc_exclusive_scan_u32(ctx, c, nb + 1, st));  // c[nb] becomes the total
     if (out_idx) hipLaunchKernelGGL(k_compact_write, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c, out_idx);
     PC_HIP(hipGetLastError());
-    uint32_t total = 0;
-    PC_HIP(hipMemcpyAsync(&total, c + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    uint32_t *total = reinterpret_cast<uint32_t *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(total, c + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));
-    *count = (int64_t)total;
+    *count = (int64_t)*total;
     return PC_OK;
 }
