@@ -89,6 +89,9 @@ struct pc_grid {
     // tile shape of the cooperative kNN kernel, chosen on first use (0: not chosen yet)
     mutable int tile[3] = {0, 0, 0};
     mutable int tile_cap = 0;
+    // the same cloud on a 4x coarser grid (and that one's own `coarse`): built for clouds that
+    // fill their box unevenly, used by the exact re-run of queries whose surroundings are sparse
+    pc_grid *coarse = nullptr;
 };
 
 // pc_sort.hip

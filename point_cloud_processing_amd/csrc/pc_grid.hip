@@ -685,12 +685,30 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         pc_grid_destroy(ctx, g);
         return rc;
     }
+    // Unevenly filled box (surfaces, clusters, clutter): add up to two coarser levels, 4x the edge
+    // each, so that a query in a sparse region finds k neighbours within one ring of SOME level.
+    if (automatic && n > 4096 && g->occupied > 0 && (double)g->occupied < 0.85 * (double)g->ncell) {
+        pc_grid *fine = g;
+        for (int lv = 1; lv <= 2; lv++) {
+            if (std::max(fine->gp.dim[0], std::max(fine->gp.dim[1], fine->gp.dim[2])) <= 4) break;
+            pc_grid *c = nullptr;
+            rc = pc_grid_build(ctx, xyz_dev, dtype, n, fine->gp.cell * 4.0, k_hint, &c, stream);
+            if (rc) {
+                pc_grid_destroy(ctx, g);
+                return rc;
+            }
+            fine->coarse = c;
+            g->bytes += c->bytes;
+            fine = c;
+        }
+    }
     *out = g;
     return PC_OK;
 }
 
 void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
     if (!g) return;
+    if (g->coarse) pc_grid_destroy(ctx, g->coarse);
     if (ctx) {
         if (g->rec) ctx->release(g->rec);
         if (g->cell_start) ctx->release(g->cell_start);

@@ -7,6 +7,14 @@
 
 enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4, M_ALL = 5 };
 
+// one resolution level of the spatial index
+struct Level {
+    GridParams gp;
+    const void *rec;
+    const uint32_t *cell_start;
+};
+constexpr int MAX_LEVELS = 3;
+
 struct ScanArgs {
     GridParams gp;
     const void *rec;
@@ -40,6 +48,9 @@ struct ScanArgs {
     int32_t *flag2_list;    // queries the wave-per-query re-run hands on to the per-lane scan
     uint32_t *flag2_count;
     uint32_t flag_cap;
+    // wave-per-query re-run: the index levels, finest first
+    Level lv[MAX_LEVELS];
+    int nlv;
 };
 
 template <typename REC>

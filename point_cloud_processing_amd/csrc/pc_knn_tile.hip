@@ -142,7 +142,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     cand_off -= row_cnt;      // exclusive
     q_off -= q_cnt;
 
-    const bool overfull = ncand > (uint32_t)A.cand_cap;
+    // over-full blocks do not fit LDS; blocks with fewer than k points cannot certify anything unless
+    // they are the whole grid: both go straight to the re-run list
+    const bool whole_grid = lo[0] == 0 && lo[1] == 0 && lo[2] == 0 && hi[0] == gp.dim[0] - 1 &&
+                            hi[1] == gp.dim[1] - 1 && hi[2] == gp.dim[2] - 1;
+    const bool overfull = ncand > (uint32_t)A.cand_cap || (ncand < (uint32_t)k && !whole_grid && A.radius2 < 0.0);
 
     // ---- stage the candidate block into LDS ------------------------------------------------------
     // flattened over the block's candidates: lane i copies candidates i, i+64, ...; the row of a

@@ -18,11 +18,9 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
     __shared__ double res_d[PC_MAX_K];
     __shared__ uint32_t res_pos[PC_MAX_K];
     const int lane = threadIdx.x;
-    const REC *rec = reinterpret_cast<const REC *>(A.rec);
-    const GridParams &gp = A.gp;
+    const REC *rec0 = reinterpret_cast<const REC *>(A.rec);
     const int k = A.k;
     const uint32_t nq = min(*A.qcount, A.flag_cap);
-    const double eps = 1e-7 * gp.cell;
     const double r2lim = A.radius2;
 
     for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {  // wave-uniform
@@ -30,31 +28,60 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         double ub = (double)A.qub[qi];
         double qx, qy, qz;
         int32_t qid;
-        RecTraits<REC>::load(rec + spos, qx, qy, qz, qid);
+        RecTraits<REC>::load(rec0 + spos, qx, qy, qz, qid);
         const double qv[3] = {qx, qy, qz};
-        int c[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double t = floor((qv[a] - gp.o[a]) * gp.s);
-            c[a] = __builtin_amdgcn_readfirstlane(!(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)t));
-        }
-        int cnt = 0;
+        int cnt = 0, lvl = 0, R = 1, retries = 0;
         bool spilled = false;
-        // ring 0 here means "the query's own row of three cells" and only serves to find an
-        // upper bound when none came with the query
-        for (int R = (ub < INFINITY) ? 1 : 0;; R++) {
+        for (;;) {
+            // ---- the block: ring R around the query's cell at level lvl -----------------------------
+            const GridParams gp = A.lv[lvl].gp;
+            const REC *rec = reinterpret_cast<const REC *>(A.lv[lvl].rec);
+            const uint32_t *cell_start = A.lv[lvl].cell_start;
+            const bool last_level = lvl == A.nlv - 1;
             int lo[3], hi[3];
+            bool whole = true;
+            double dmin = INFINITY;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                const int Ra = (R == 0 && a > 0) ? 0 : (R == 0 ? 1 : R);
-                lo[a] = max(c[a] - Ra, 0);
-                hi[a] = min(c[a] + Ra, gp.dim[a] - 1);
+                const double t = floor((qv[a] - gp.o[a]) * gp.s);
+                const int c = __builtin_amdgcn_readfirstlane(
+                    !(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)t));
+                lo[a] = max(c - R, 0);
+                hi[a] = min(c + R, gp.dim[a] - 1);
+                if (lo[a] > 0) {
+                    whole = false;
+                    dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)lo[a] * gp.cell));
+                }
+                if (hi[a] < gp.dim[a] - 1) {
+                    whole = false;
+                    dmin = fmin(dmin, (gp.o[a] + (double)(hi[a] + 1) * gp.cell) - qv[a]);
+                }
             }
-            uint32_t m = 0;  // survivors so far (wave-uniform)
-            for (int z = lo[2]; z <= hi[2]; z++)
-                for (int y = lo[1]; y <= hi[1]; y++) {
-                    const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
-                    const uint32_t jb = A.cell_start[row + lo[0]], je = A.cell_start[row + hi[0] + 1];
+            double b2 = INFINITY;  // no point outside the block is closer than sqrt(b2)
+            if (!whole) {
+                const double b = dmin - 1e-7 * gp.cell;
+                b2 = b > 0 ? b * b : 0.0;
+            }
+            const bool can_end_short = whole || (r2lim >= 0.0 && b2 >= r2lim);
+            const int nry = hi[1] - lo[1] + 1, nrows = nry * (hi[2] - lo[2] + 1);
+            // population of the block: lanes over rows
+            uint32_t total = 0;
+            for (int r = lane; r < nrows; r += PC_WAVE) {
+                const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
+                total += cell_start[row + hi[0] + 1] - cell_start[row + lo[0]];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+            total = __builtin_amdgcn_readfirstlane(total);
+
+            bool certified = false;
+            if (total >= (uint32_t)k || can_end_short) {
+                // ---- survivors: candidates not farther than the bound, compacted into LDS ---------------
+                const double ub_in = ub;
+                uint32_t m = 0;
+                for (int r = 0; r < nrows; r++) {
+                    const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
+                    const uint32_t jb = cell_start[row + lo[0]], je = cell_start[row + hi[0] + 1];
                     for (uint32_t j0 = jb; j0 < je; j0 += PC_WAVE) {
                         const uint32_t j = j0 + lane;
                         bool keep = false;
@@ -79,83 +106,104 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                         m += __popcll(bal);
                     }
                 }
-            __syncthreads();
-            if (m > SCAP) {
-                // too many survivors for LDS: tighten the bound from the ones held, or give up
-                // after one attempt (heavy ties: every survivor at the same distance)
-                spilled = true;
-            }
-            const uint32_t mm = min(m, (uint32_t)SCAP);
-            // rank the held survivors by (d2, original index)
-            double kth = INFINITY;
-            for (uint32_t base = 0; base < mm; base += PC_WAVE) {
-                const uint32_t i = base + lane;
-                const bool have = i < mm;
-                const double di = have ? sv_d[i] : INFINITY;
-                const int32_t ii = have ? sv_id[i] : 0x7fffffff;
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < mm; j++) {
-                    const double dj = sv_d[j];
-                    const int32_t ij = sv_id[j];
-                    rank += (dj < di || (dj == di && ij < ii)) ? 1u : 0u;
-                }
-                if (have && rank < (uint32_t)k) {
-                    res_d[rank] = di;
-                    res_pos[rank] = sv_pos[i];
-                }
-            }
-            __syncthreads();
-            cnt = (int)min(mm, (uint32_t)k);
-            if (cnt == k) kth = res_d[k - 1];
-            if (spilled) {
-                if (cnt == k && kth < ub) {
-                    // the k-th of the held survivors bounds the true k-th: retry this ring with it
-                    ub = kth;
-                    spilled = false;
-                    R--;
-                    __syncthreads();
-                    continue;
-                }
-                break;  // cannot shrink: hand over to the per-lane scan
-            }
-            if (R == 0) {
-                if (cnt == k) ub = kth;
                 __syncthreads();
-                continue;  // now scan ring 1 with (or still without) a bound
-            }
-            bool whole = true;
-            double dmin = INFINITY;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                if (lo[a] > 0) {
-                    whole = false;
-                    dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)lo[a] * gp.cell));
+                uint32_t mm = min(m, (uint32_t)SCAP);
+                // Thin the held survivors inside LDS before ranking them (ranking is quadratic): the
+                // k-th smallest of ANY 64 of them bounds the true k-th distance, so everything
+                // farther than it can go.  Repeat while that still removes something.
+                while (mm > 2 * PC_WAVE) {
+                    const double di = sv_d[lane];
+                    const int32_t ii = sv_id[lane];
+                    int rank = 0;
+                    for (int j = 0; j < PC_WAVE; j++) {
+                        const double dj = __shfl(di, j, 64);
+                        const int32_t ij = __shfl(ii, j, 64);
+                        rank += (dj < di || (dj == di && ij < ii)) ? 1 : 0;
+                    }
+                    const unsigned long long sel = __ballot(rank == k - 1);
+                    const double cut = __shfl(di, __ffsll((long long)sel) - 1, 64);  // k <= 64: one lane has it
+                    uint32_t kept = 0;
+                    for (uint32_t base = 0; base < mm; base += PC_WAVE) {
+                        const uint32_t i = base + lane;
+                        const bool have = i < mm;
+                        const double d = have ? sv_d[i] : 0.0;
+                        const uint32_t p = have ? sv_pos[i] : 0u;
+                        const int32_t id = have ? sv_id[i] : 0;
+                        const bool keep = have && d <= cut;
+                        const unsigned long long bal = __ballot(keep);
+                        const uint32_t at = kept + __popcll(bal & ((1ull << lane) - 1ull));
+                        __syncthreads();  // every lane has read its entry before any slot is rewritten
+                        if (keep) {
+                            sv_d[at] = d;
+                            sv_pos[at] = p;
+                            sv_id[at] = id;
+                        }
+                        kept += __popcll(bal);
+                    }
+                    __syncthreads();
+                    ub = fmin(ub, cut);  // a bound of the true k-th distance, for retries and later rings too
+                    if (kept == mm) break;  // ties only: nothing left to remove
+                    mm = kept;
                 }
-                if (hi[a] < gp.dim[a] - 1) {
-                    whole = false;
-                    dmin = fmin(dmin, (gp.o[a] + (double)(hi[a] + 1) * gp.cell) - qv[a]);
+                // rank the held survivors by (d2, original index)
+                for (uint32_t base = 0; base < mm; base += PC_WAVE) {
+                    const uint32_t i = base + lane;
+                    const bool have = i < mm;
+                    const double di = have ? sv_d[i] : INFINITY;
+                    const int32_t ii = have ? sv_id[i] : 0x7fffffff;
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < mm; j++) {
+                        const double dj = sv_d[j];
+                        const int32_t ij = sv_id[j];
+                        rank += (dj < di || (dj == di && ij < ii)) ? 1u : 0u;
+                    }
+                    if (have && rank < (uint32_t)k) {
+                        res_d[rank] = di;
+                        res_pos[rank] = sv_pos[i];
+                    }
                 }
+                __syncthreads();
+                cnt = (int)min(mm, (uint32_t)k);
+                const double kth = cnt == k ? res_d[k - 1] : INFINITY;
+                __syncthreads();
+                if (m > (uint32_t)SCAP) {
+                    // LDS held only part of the survivors: their k-th bounds the true k-th, so
+                    // retry the same block with it; without progress (ties) hand the query on
+                    if (cnt == k) ub = fmin(ub, kth);
+                    if (ub < ub_in && retries < 8) {
+                        retries++;
+                        continue;
+                    }
+                    spilled = true;
+                    break;
+                }
+                certified = can_end_short || (cnt == k && kth <= b2);
+                if (certified) {
+                    // results refer to this level's records
+                    if (lane == 0) {
+                        emit_result<MODE>(A, (int64_t)qid, cnt,
+                                          [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
+                                              d = res_d[s];
+                                              RecTraits<REC>::load(rec + res_pos[s], x, y, z, id);
+                                          });
+                    }
+                    break;
+                }
+                if (cnt == k) ub = fmin(ub, kth);
             }
-            if (whole) break;
-            const double b = dmin - eps;
-            if (b > 0) {
-                const double b2 = b * b;
-                if (r2lim >= 0.0 && b2 >= r2lim) break;
-                if (cnt == k && kth <= b2) break;
+            // widen: rings 1 and 2 at each level in turn (block edges 3, 5 | 12, 20 | 48, 80 ... fine
+            // cells), then ever larger rings at the coarsest level
+            if (!last_level && R >= 2) {
+                lvl++;
+                R = 1;
+            } else {
+                R++;
             }
-            if (cnt == k) ub = fmin(ub, kth);
-            __syncthreads();
+            retries = 0;
         }
-        if (spilled) {
-            if (lane == 0) {
-                const uint32_t p = atomicAdd(A.flag2_count, 1u);
-                if (p < A.flag_cap) A.flag2_list[p] = (int32_t)spos;
-            }
-        } else if (lane == 0) {
-            emit_result<MODE>(A, (int64_t)qid, cnt, [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
-                d = res_d[s];
-                RecTraits<REC>::load(rec + res_pos[s], x, y, z, id);
-            });
+        if (spilled && lane == 0) {
+            const uint32_t p = atomicAdd(A.flag2_count, 1u);
+            if (p < A.flag_cap) A.flag2_list[p] = (int32_t)spos;
         }
         __syncthreads();
     }
@@ -176,7 +224,15 @@ void launch_wave(int mode, unsigned nb, hipStream_t st, const ScanArgs &A) {
 }  // namespace
 
 // Answers A.qlist / A.qub / A.qcount; queries it cannot hold go to A.flag2_list / A.flag2_count.
-int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A, hipStream_t st) {
+int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A0, hipStream_t st) {
+    ScanArgs A = A0;
+    A.nlv = 0;
+    for (const pc_grid *l = g; l && A.nlv < MAX_LEVELS; l = l->coarse) {
+        A.lv[A.nlv].gp = l->gp;
+        A.lv[A.nlv].rec = l->rec;
+        A.lv[A.nlv].cell_start = l->cell_start;
+        A.nlv++;
+    }
     const unsigned nb = 8192;  // persistent waves; each strides over the list
     if (g->dtype == PC_F32)
         launch_wave<Rec32>(mode, nb, st, A);
