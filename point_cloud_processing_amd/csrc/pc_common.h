@@ -76,12 +76,22 @@ struct GridParams {
     int32_t dim[3];
 };
 
+// Cell key -> first sorted position of that cell.  Dense form: a table of ncell + 1 offsets.
+// Sparse form (huge, mostly empty grids): no table; the sorted per-point cell keys are searched.
+struct CellIndex {
+    const uint32_t *table;  // ncell + 1 entries, or NULL
+    const uint32_t *keys;   // n sorted cell keys (sparse form)
+    uint32_t n;
+};
+
 struct pc_grid {
     int64_t n = 0;
     int dtype = PC_F32;
     GridParams gp{};
     void *rec = nullptr;          // Rec32[n] or Rec64[n]
-    uint32_t *cell_start = nullptr;  // ncell + 1
+    uint32_t *cell_start = nullptr;  // ncell + 1 (dense form), or NULL
+    uint32_t *keys = nullptr;        // n sorted cell keys (sparse form), or NULL
+    CellIndex index() const { return CellIndex{cell_start, keys, (uint32_t)n}; }
     int32_t *perm = nullptr;      // sorted position -> original index
     int64_t ncell = 0;
     size_t bytes = 0;
@@ -89,9 +99,13 @@ struct pc_grid {
     // tile shape of the cooperative kNN kernel, chosen on first use (0: not chosen yet)
     mutable int tile[3] = {0, 0, 0};
     mutable int tile_cap = 0;
-    // the same cloud on a 4x coarser grid (and that one's own `coarse`): built for clouds that
+    mutable uint32_t *tile_list = nullptr;  // sparse form: linear ids of the occupied tiles
+    mutable int64_t tile_count = 0;
+    // the same cloud on a 2x coarser grid (and that one's own `coarse`): built for clouds that
     // fill their box unevenly, used by the exact re-run of queries whose surroundings are sparse
     pc_grid *coarse = nullptr;
+    int level = 0;        // 0: finest
+    bool uneven = false;  // part of a multi-level index (set on every level)
 };
 
 // pc_sort.hip
@@ -99,6 +113,7 @@ int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *k
                         int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp);
 int pc_radix_sort_pairs32(pc_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
                           int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp);
+int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_idx, int64_t *count, hipStream_t st);
 int pc_exclusive_scan_u32(pc_ctx *ctx, uint32_t *data, int64_t n, hipStream_t st);
 // flags (0/1 bytes) -> ascending indices of the set flags; *count on host (synchronises)
 int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_idx, int64_t *count, hipStream_t st);

@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void k_cell_runs(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ keys, int64_t n,
                                                     unsigned long long *__restrict__ stats) {
     unsigned long long sq = 0, runs = 0;
+    __shared__ unsigned long long hist[32];
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
     // grid-stride: a few thousand atomics in total instead of one pair per wave
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t key = keys[i];
@@ -285,8 +288,12 @@ __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ 
             }
             sq += (unsigned long long)(e - i) * (unsigned long long)(e - i);
             runs += 1;
+            // point-weighted histogram of the run length: bin b holds lengths in [2^b, 2^(b+1))
+            atomicAdd(&hist[min(31, 63 - __clzll((unsigned long long)(e - i)))], (unsigned long long)(e - i));
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], hist[threadIdx.x]);
     __shared__ unsigned long long red[2][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -583,7 +590,8 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             if (f > 0.1 && f < 10.0) cell *= f;
         }
     }
-    // dense cell table, capped at 16 n + 4096 cells (and below 2^32: u32 cell keys)
+    // u32 cell keys: below 2^32 cells.  A dense offset table is kept while it stays within
+    // 8 n + 4096 cells; emptier grids use the sparse index (binary search over the sorted keys).
     auto fit_dims = [&](double c, int32_t dim[3]) {
         for (;;) {
             double tot = 1.0;
@@ -592,7 +600,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
                 dim[a] = (int32_t)d;
                 tot *= d;
             }
-            if (tot <= std::min(16.0 * (double)n + 4096.0, 4.0e9)) return c;
+            if (tot <= 4.0e9) return c;
             c *= 1.1;
         }
     };
@@ -607,7 +615,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             keys2(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1));
         Scratch vals(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1)),
             vals2(ctx, sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1));
-        Scratch stats(ctx, 256);
+        Scratch stats(ctx, 512);
         if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok() || !stats.ok()) {
             rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
             break;
@@ -627,24 +635,36 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
                                    (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
             rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
                                        vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
-            if (rc || !automatic || attempt >= 5) break;
+            if (rc || !automatic || attempt >= 8) break;
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
-            if (hipMemsetAsync(stats.p, 0, 16, st) != hipSuccess) break;
+            if (hipMemsetAsync(stats.p, 0, 34 * 8, st) != hipSuccess) break;
             hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st,
                                in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>(), n,
                                stats.as<unsigned long long>());
-            if (hipMemcpyAsync(hs, stats.p, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            if (hipMemcpyAsync(hs, stats.p, 34 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) {
                 rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
                 break;
             }
-            const double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
+            double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
+            // ... and the occupancy nine points in ten stay below (upper edge of their histogram bin):
+            // the finest level has to suit the DENSE parts, coarser levels take care of the rest
+            double p90 = 1.0;
+            unsigned long long acc = 0;
+            for (int b = 0; b < 32; b++) {
+                acc += hs[2 + b];
+                if ((double)acc >= 0.9 * (double)n) {
+                    p90 = ldexp(2.0, b);
+                    break;
+                }
+            }
+            (void)p90;
             if (seen <= 2.0 * (target + 1.0)) break;
             int32_t dim2[3];
             const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
             const double got = fit_dims(want, dim2);
-            if (got > 0.93 * cell) break;  // the table cap binds: no finer grid available
+            if (got > 0.93 * cell) break;  // the key range binds: no finer grid available
             cell = got;
             for (int a = 0; a < 3; a++) g->gp.dim[a] = dim2[a];
         }
@@ -652,25 +672,39 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         g->gp.cell = cell;
         g->gp.s = 1.0 / cell;
         g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
-        cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
+        const bool dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
+        cs_bytes = dense ? sizeof(uint32_t) * (size_t)(g->ncell + 1) : sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1);
         g->rec = ctx->alloc(rec_bytes);
-        g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
         g->perm = (int32_t *)ctx->alloc(perm_bytes);
+        if (dense)
+            g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
+        else
+            g->keys = (uint32_t *)ctx->alloc(cs_bytes);
         g->bytes = rec_bytes + cs_bytes + perm_bytes;
-        if (!g->rec || !g->cell_start || !g->perm) {
+        if (!g->rec || !g->perm || (dense ? !g->cell_start : !g->keys)) {
             rc = pc_fail(ctx, PC_NOMEM, "grid buffers");
             break;
         }
-        if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
-            rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
+        if (n == 0) {
+            if (dense && hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess)
+                rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
             break;
         }
-        if (n == 0) break;
-        // cell_start = exclusive scan of the per-cell counts (run lengths of the sorted keys)
-        hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                           in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>(), n, g->cell_start);
-        rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
-        if (rc) break;
+        const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
+        if (dense) {
+            // cell_start = exclusive scan of the per-cell counts (run lengths of the sorted keys)
+            if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
+                rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
+                break;
+            }
+            hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
+            rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
+            if (rc) break;
+        } else if (hipMemcpyAsync(g->keys, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st) !=
+                   hipSuccess) {
+            rc = pc_fail(ctx, PC_HIP_ERROR, "copy sorted keys");
+            break;
+        }
         const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
         if (dtype == PC_F32)
             hipLaunchKernelGGL((k_gather_records<float, Rec32>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
@@ -685,19 +719,22 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         pc_grid_destroy(ctx, g);
         return rc;
     }
-    // Unevenly filled box (surfaces, clusters, clutter): add up to two coarser levels, 4x the edge
+    // Unevenly filled box (surfaces, clusters, clutter): add up to five coarser levels, twice the edge
     // each, so that a query in a sparse region finds k neighbours within one ring of SOME level.
     if (automatic && n > 4096 && g->occupied > 0 && (double)g->occupied < 0.85 * (double)g->ncell) {
         pc_grid *fine = g;
-        for (int lv = 1; lv <= 2; lv++) {
+        g->uneven = true;
+        for (int lv = 1; lv < 6; lv++) {
             if (std::max(fine->gp.dim[0], std::max(fine->gp.dim[1], fine->gp.dim[2])) <= 4) break;
             pc_grid *c = nullptr;
-            rc = pc_grid_build(ctx, xyz_dev, dtype, n, fine->gp.cell * 4.0, k_hint, &c, stream);
+            rc = pc_grid_build(ctx, xyz_dev, dtype, n, fine->gp.cell * 2.0, k_hint, &c, stream);
             if (rc) {
                 pc_grid_destroy(ctx, g);
                 return rc;
             }
             fine->coarse = c;
+            c->uneven = true;
+            c->level = lv;
             g->bytes += c->bytes;
             fine = c;
         }
@@ -712,6 +749,8 @@ void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
     if (ctx) {
         if (g->rec) ctx->release(g->rec);
         if (g->cell_start) ctx->release(g->cell_start);
+        if (g->keys) ctx->release(g->keys);
+        if (g->tile_list) ctx->release(g->tile_list);
         if (g->perm) ctx->release(g->perm);
     }
     delete g;

@@ -9,6 +9,8 @@
 // slot).  All kernels are HBM/LDS/VALU work; nothing here is a dense contraction.
 #include <math.h>
 
+#include <stdio.h>
+
 #include <algorithm>
 
 #include "pc_knn_dev.h"
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_scan(ScanArgs A) {
                             x0 = x1 = (s == 0) ? c[0] - R : c[0] + R;
                             if (x0 < 0 || x0 >= gp.dim[0]) continue;
                         }
-                        const uint32_t jb = A.cell_start[row + x0], je = A.cell_start[row + x1 + 1];
+                        const uint32_t jb = cell_begin(A.ci, row + x0), je = cell_begin(A.ci, row + x1 + 1);
                         for (uint32_t j = jb; j < je; j++) {
                             double px, py, pz;
                             int32_t pid;
@@ -177,6 +179,14 @@ int launch_scan(pc_ctx *ctx, const pc_grid *g, int qdtype, const ScanArgs &A0, h
             hipLaunchKernelGGL((k_scan<Rec64, double, MODE>), dim3(nb), dim3(PC_WAVE), lds, st, A);
     }
     PC_HIP(hipGetLastError());
+    if (tiled && getenv("PC_AMD_DEBUG")) {  // development aid: how many queries each re-run stage received
+        uint32_t c[32];
+        PC_HIP(hipStreamSynchronize(st));
+        PC_HIP(hipMemcpy(c, A.flag_count, sizeof(c), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pc_amd] n=%lld k=%d tile=%dx%dx%d cap=%d tiles=%lld: wave-per-query %u, per-lane %u\n",
+                (long long)A.nq, A.k, A.tile[0], A.tile[1], A.tile[2], A.cand_cap,
+                (long long)(g->tile_list ? g->tile_count : (int64_t)A.ntile[0] * A.ntile[1] * A.ntile[2]), c[0], c[16]);
+    }
     return PC_OK;
 }
 
@@ -184,7 +194,7 @@ ScanArgs base_args(const pc_grid *g) {
     ScanArgs A{};
     A.gp = g->gp;
     A.rec = g->rec;
-    A.cell_start = g->cell_start;
+    A.ci = g->index();
     A.radius2 = -1.0;
     return A;
 }

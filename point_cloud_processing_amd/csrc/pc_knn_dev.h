@@ -5,20 +5,34 @@
 
 #include "pc_common.h"
 
+// first sorted position whose cell key is >= key (key may be ncell: one past the last cell)
+__device__ inline uint32_t cell_begin(const CellIndex &ci, int64_t key) {
+    if (ci.table) return ci.table[key];
+    uint32_t lo = 0, hi = ci.n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((int64_t)ci.keys[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4, M_ALL = 5 };
 
 // one resolution level of the spatial index
 struct Level {
     GridParams gp;
     const void *rec;
-    const uint32_t *cell_start;
+    CellIndex ci;
 };
-constexpr int MAX_LEVELS = 3;
+constexpr int MAX_LEVELS = 6;
 
 struct ScanArgs {
     GridParams gp;
     const void *rec;
-    const uint32_t *cell_start;
+    CellIndex ci;
     const void *queries;  // NULL: self-query over sorted positions
     int64_t s_begin;      // first sorted position (self) / first query row (external)
     int64_t nq;
@@ -42,6 +56,12 @@ struct ScanArgs {
     int ntile[3];           // tiles per axis
     int64_t s_end;          // self-query range end (sorted position)
     int cand_cap;           // candidates the LDS block holds
+    const uint32_t *tile_list;  // occupied tiles (sparse index), or NULL: blockIdx is the tile id
+    // multi-level passes: per-point flags and bounds, indexed by ORIGINAL point index
+    const uint8_t *qflag_in;    // NULL: every point of the range is a query; else only flagged points
+    uint8_t *qflag_out;         // where uncertified queries are flagged for the next (coarser) pass;
+                                // NULL on the last pass, which appends to flag_list instead
+    float *qub_arr;             // upper bound of the k-th squared distance found so far
     int32_t *flag_list;     // queries handed to the exact re-run (one wave per query)
     float *flag_ub;
     uint32_t *flag_count;

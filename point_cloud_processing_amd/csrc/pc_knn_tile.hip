@@ -15,6 +15,10 @@
 // The consumers (mean distance, normal, ...) run on the certified list while the candidates
 // are still in LDS.  HBM traffic per query is therefore the algorithmic minimum plus the halo
 // re-reads served by L2.
+#include <stdio.h>
+
+#include <vector>
+
 #include "pc_knn_dev.h"
 
 namespace {
@@ -90,11 +94,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     const int k = A.k;
 
     // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
-    int t = blockIdx.x;
-    const int tx = t % A.ntile[0];
+    int64_t t = A.tile_list ? (int64_t)A.tile_list[blockIdx.x] : (int64_t)blockIdx.x;
+    const int tx = (int)(t % A.ntile[0]);
     t /= A.ntile[0];
-    const int ty = t % A.ntile[1];
-    const int tz = t / A.ntile[1];
+    const int ty = (int)(t % A.ntile[1]);
+    const int tz = (int)(t / A.ntile[1]);
     const int c0[3] = {tx * A.tile[0], ty * A.tile[1], tz * A.tile[2]};  // first cell of the tile
     int c1[3], lo[3], hi[3];                                              // last cell; block bounds
 #pragma unroll
@@ -115,15 +119,16 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     if (lane < nrows) {
         const int y = lo[1] + lane % nry, z = lo[2] + lane / nry;
         const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
-        row_begin = A.cell_start[row + lo[0]];
-        row_cnt = A.cell_start[row + hi[0] + 1] - row_begin;
+        row_begin = cell_begin(A.ci, row + lo[0]);
+        row_cnt = cell_begin(A.ci, row + hi[0] + 1) - row_begin;
         if (y >= c0[1] && y <= c1[1] && z >= c0[2] && z <= c1[2]) {  // a row of the tile itself
-            q_begin = A.cell_start[row + c0[0]];
-            q_cnt = A.cell_start[row + c1[0] + 1] - q_begin;
-            // restrict to the caller's sorted-position range
-            const int64_t b = max((int64_t)q_begin, A.s_begin), e = min((int64_t)q_begin + q_cnt, A.s_end);
-            q_begin = (uint32_t)b;
-            q_cnt = e > b ? (uint32_t)(e - b) : 0u;
+            q_begin = cell_begin(A.ci, row + c0[0]);
+            q_cnt = cell_begin(A.ci, row + c1[0] + 1) - q_begin;
+            if (!A.qflag_in) {  // first pass: restrict to the caller's sorted-position range
+                const int64_t b = max((int64_t)q_begin, A.s_begin), e = min((int64_t)q_begin + q_cnt, A.s_end);
+                q_begin = (uint32_t)b;
+                q_cnt = e > b ? (uint32_t)(e - b) : 0u;
+            }
         }
     }
     // inclusive prefix sums over the rows (wave scan)
@@ -141,6 +146,30 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     if (nquery == 0) return;  // wave-uniform
     cand_off -= row_cnt;      // exclusive
     q_off -= q_cnt;
+    if (A.qflag_in && (ncand > (uint32_t)A.cand_cap)) return;  // flagged points of an over-full block stay flagged
+    if (A.qflag_in) {
+        // later passes answer only the points an earlier pass flagged: leave if the tile has none
+        bool any = false;
+        for (uint32_t qbase = 0; qbase < nquery; qbase += PC_WAVE) {
+            const uint32_t qo = qbase + lane;
+            uint32_t sp = 0;
+            bool have = false;
+            for (int r = 0; r < nrows; r++) {
+                const uint32_t ob = __shfl(q_off, r, 64), oc = __shfl(q_cnt, r, 64), gb = __shfl(q_begin, r, 64);
+                if (qo < nquery && qo >= ob && qo < ob + oc) {
+                    sp = gb + (qo - ob);
+                    have = true;
+                }
+            }
+            if (have) {
+                double x, y, z;
+                int32_t id;
+                RecTraits<REC>::load(rec + sp, x, y, z, id);
+                any = any || A.qflag_in[id] != 0;
+            }
+        }
+        if (!__any(any)) return;
+    }
 
     // over-full blocks do not fit LDS; blocks with fewer than k points cannot certify anything unless
     // they are the whole grid: both go straight to the re-run list
@@ -184,7 +213,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         const int r = e / (nx + 1), i = e - r * (nx + 1);
         const int y = lo[1] + r % nry, z = lo[2] + r / nry;
         const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
-        cell_off[r * (MAX_NX + 1) + i] = (uint16_t)(row_off[r] + (A.cell_start[row + lo[0] + i] - row_src[r]));
+        cell_off[r * (MAX_NX + 1) + i] = (uint16_t)(row_off[r] + (cell_begin(A.ci, row + lo[0] + i) - row_src[r]));
     }
     __syncthreads();
 
@@ -200,19 +229,29 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             const uint32_t ob = __shfl(q_off, r, 64), oc = __shfl(q_cnt, r, 64), gb = __shfl(q_begin, r, 64);
             if (active && qo >= ob && qo < ob + oc) spos = gb + (qo - ob);
         }
+        double qxd = 0.0, qyd = 0.0, qzd = 0.0;
+        int32_t qid = 0;
+        bool live = active;  // a query this pass has to answer
+        if (active) {
+            RecTraits<REC>::load(rec + spos, qxd, qyd, qzd, qid);
+            if (A.qflag_in) live = A.qflag_in[qid] != 0;
+        }
+        if (!__any(live)) continue;
         if (overfull) {
-            if (active) {
-                const uint32_t p = atomicAdd(A.flag_count, 1u);
-                if (p < A.flag_cap) {
-                    A.flag_list[p] = (int32_t)spos;
-                    A.flag_ub[p] = INFINITY;
+            if (live) {
+                if (A.qflag_out) {
+                    A.qflag_out[qid] = 1;
+                    if (!A.qflag_in) A.qub_arr[qid] = INFINITY;
+                } else {
+                    const uint32_t p = atomicAdd(A.flag_count, 1u);
+                    if (p < A.flag_cap) {
+                        A.flag_list[p] = (int32_t)spos;
+                        A.flag_ub[p] = A.qflag_in ? A.qub_arr[qid] : INFINITY;
+                    }
                 }
             }
             continue;
         }
-        double qxd = 0.0, qyd = 0.0, qzd = 0.0;
-        int32_t qid = 0;
-        if (active) RecTraits<REC>::load(rec + spos, qxd, qyd, qzd, qid);
         // filter coordinates: the stored fp32 values, or fp32 offsets from the block origin
         const float qx = TileRec<REC>::kRelative ? (float)(qxd - org[0]) : (float)qxd;
         const float qy = TileRec<REC>::kRelative ? (float)(qyd - org[1]) : (float)qyd;
@@ -246,7 +285,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         for (int seg = 0; seg < 9; seg++) {
             const int y = qc[1] + seg % 3 - 1, z = qc[2] + seg / 3 - 1;
             uint32_t st = 0, ln = 0;
-            if (active && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2]) {
+            if (live && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2]) {
                 const int r = (y - lo[1]) + nry * (z - lo[2]);
                 st = cell_off[r * (MAX_NX + 1) + i0];
                 ln = cell_off[r * (MAX_NX + 1) + i1] - st;
@@ -281,7 +320,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             }
         }
 #undef PC_KEY
-        if (!active) continue;
+        if (!live) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
         const double qv[3] = {qxd, qyd, qzd};
@@ -348,13 +387,21 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         }
         const bool ok = nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim);
         if (!ok) {
-            const uint32_t p = atomicAdd(A.flag_count, 1u);
-            if (p < A.flag_cap) {
-                A.flag_list[p] = (int32_t)spos;
-                A.flag_ub[p] = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
+            float ubf = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
+            if (A.qflag_in) ubf = fminf(ubf, A.qub_arr[qid]);
+            if (A.qflag_out) {
+                A.qflag_out[qid] = 1;
+                A.qub_arr[qid] = ubf;
+            } else {
+                const uint32_t p = atomicAdd(A.flag_count, 1u);
+                if (p < A.flag_cap) {
+                    A.flag_list[p] = (int32_t)spos;
+                    A.flag_ub[p] = ubf;
+                }
             }
             continue;
         }
+        if (A.qflag_in && A.qflag_out) A.qflag_out[qid] = 0;  // answered: later passes skip it
         // The list is already ordered by the truncated fp32 key, so the exact (d2, index) order
         // differs from it by a few adjacent transpositions at most: bubble passes until no lane of
         // the wave swaps (excluded entries carry d2 = +inf and sink to the end).
@@ -392,63 +439,106 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     }
 }
 
-// ---- tile shape probe ------------------------------------------------------------------------------
-// The best tile shape depends on how the cloud fills space (a surface crosses ~t^2 of a t^3 tile's
-// cells, a volume fills all of them).  Sample points, and for every candidate shape measure the
-// population of the tile and of the tile+halo block the point lives in.  Per shape:
-//   acc[0] = sum of lane efficiency  pop / (64 * ceil(pop / 64))   (0 when the block overflows LDS)
-//   acc[1] = sum of block population, acc[2] = sum of its square.
-constexpr int NSHAPE = 12;
-__constant__ int c_shapes[NSHAPE][3] = {{1, 1, 1}, {2, 1, 1}, {2, 2, 1}, {2, 2, 2}, {3, 2, 2}, {3, 3, 2},
-                                        {3, 3, 3}, {4, 3, 3}, {4, 4, 3}, {4, 4, 4}, {5, 5, 4}, {5, 6, 6}};
-const int h_shapes[NSHAPE][3] = {{1, 1, 1}, {2, 1, 1}, {2, 2, 1}, {2, 2, 2}, {3, 2, 2}, {3, 3, 2},
-                                 {3, 3, 3}, {4, 3, 3}, {4, 4, 3}, {4, 4, 4}, {5, 5, 4}, {5, 6, 6}};
+// ---- occupied tiles of a sparse grid -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_key_heads(const uint32_t *__restrict__ keys, int64_t n,
+                                                    uint8_t *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
 
-template <typename REC>
-__global__ __launch_bounds__(256) void k_tile_probe(GridParams gp, const REC *__restrict__ rec,
-                                                     const uint32_t *__restrict__ cell_start, int64_t n,
-                                                     int64_t stride, int nsample, float *__restrict__ acc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nsample) return;
-    const int64_t s = min((int64_t)i * stride, n - 1);
-    double qf[3];
-    int32_t qid;
-    RecTraits<REC>::load(rec + s, qf[0], qf[1], qf[2], qid);
-    int c[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const double t = floor((qf[a] - gp.o[a]) * gp.s);
-        c[a] = !(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)t);
-    }
-    for (int sh = 0; sh < NSHAPE; sh++) {
-        int t0[3], t1[3], lo[3], hi[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            t0[a] = (c[a] / c_shapes[sh][a]) * c_shapes[sh][a];
-            t1[a] = min(t0[a] + c_shapes[sh][a], gp.dim[a]) - 1;
-            lo[a] = max(t0[a] - 1, 0);
-            hi[a] = min(t1[a] + 1, gp.dim[a] - 1);
+__global__ __launch_bounds__(256) void k_tile_ids(const uint32_t *__restrict__ keys, const int32_t *__restrict__ heads,
+                                                   int64_t m, int dx, int dy, int tx, int ty, int tz, int ntx, int nty,
+                                                   uint32_t *__restrict__ out, uint32_t *__restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    uint32_t key = keys[heads[i]];
+    const uint32_t x = key % (uint32_t)dx;
+    key /= (uint32_t)dx;
+    const uint32_t y = key % (uint32_t)dy, z = key / (uint32_t)dy;
+    out[i] = ((z / tz) * (uint32_t)nty + (y / ty)) * (uint32_t)ntx + (x / tx);
+    vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_take(const uint32_t *__restrict__ src, const int32_t *__restrict__ idx,
+                                               int64_t m, uint32_t *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) dst[i] = src[idx[i]];
+}
+
+// unique tile ids of the occupied cells, ascending (sparse grids only)
+int build_tile_list(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
+    const int64_t n = g->n;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    Scratch flags(ctx, (size_t)n), heads(ctx, sizeof(int32_t) * (size_t)n);
+    if (!flags.ok() || !heads.ok()) return pc_fail(ctx, PC_NOMEM, "tile list");
+    hipLaunchKernelGGL(k_key_heads, dim3(nb), dim3(256), 0, st, g->keys, n, flags.as<uint8_t>());
+    int64_t u = 0;
+    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), n, heads.as<int32_t>(), &u, st));
+    Scratch tid(ctx, sizeof(uint32_t) * (size_t)u), tid2(ctx, sizeof(uint32_t) * (size_t)u);
+    Scratch v(ctx, sizeof(uint32_t) * (size_t)u), v2(ctx, sizeof(uint32_t) * (size_t)u);
+    if (!tid.ok() || !tid2.ok() || !v.ok() || !v2.ok()) return pc_fail(ctx, PC_NOMEM, "tile list");
+    const int ntx = (g->gp.dim[0] + g->tile[0] - 1) / g->tile[0], nty = (g->gp.dim[1] + g->tile[1] - 1) / g->tile[1],
+              ntz = (g->gp.dim[2] + g->tile[2] - 1) / g->tile[2];
+    const unsigned ub = (unsigned)((u + 255) / 256);
+    hipLaunchKernelGGL(k_tile_ids, dim3(ub), dim3(256), 0, st, g->keys, heads.as<int32_t>(), u, g->gp.dim[0],
+                       g->gp.dim[1], g->tile[0], g->tile[1], g->tile[2], ntx, nty, tid.as<uint32_t>(), v.as<uint32_t>());
+    uint64_t nt = (uint64_t)ntx * nty * ntz;
+    int bits = 1;
+    while (bits < 32 && (nt >> bits)) bits++;
+    bool in_tmp = false;
+    PC_TRY(pc_radix_sort_pairs32(ctx, tid.as<uint32_t>(), v.as<uint32_t>(), tid2.as<uint32_t>(), v2.as<uint32_t>(), u,
+                                 bits, st, &in_tmp));
+    const uint32_t *sorted = in_tmp ? tid2.as<uint32_t>() : tid.as<uint32_t>();
+    hipLaunchKernelGGL(k_key_heads, dim3(ub), dim3(256), 0, st, sorted, u, flags.as<uint8_t>());
+    int64_t nocc = 0;
+    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), u, heads.as<int32_t>(), &nocc, st));
+    g->tile_list = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(nocc, 1));
+    if (!g->tile_list) return pc_fail(ctx, PC_NOMEM, "tile list");
+    hipLaunchKernelGGL(k_take, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, sorted, heads.as<int32_t>(), nocc,
+                       g->tile_list);
+    PC_HIP(hipGetLastError());
+    PC_HIP(hipStreamSynchronize(st));
+    g->tile_count = nocc;
+    return PC_OK;
+}
+
+__global__ __launch_bounds__(256) void k_tile_nonempty(GridParams gp, CellIndex ci, int tx, int ty, int tz, int ntx,
+                                                        int nty, int64_t ntile, uint8_t *__restrict__ flags) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntile) return;
+    const int x0 = (int)(t % ntx) * tx, y0 = (int)((t / ntx) % nty) * ty, z0 = (int)(t / ((int64_t)ntx * nty)) * tz;
+    const int x1 = min(x0 + tx, gp.dim[0]), y1 = min(y0 + ty, gp.dim[1]), z1 = min(z0 + tz, gp.dim[2]);
+    uint32_t pop = 0;
+    for (int z = z0; z < z1; z++)
+        for (int y = y0; y < y1; y++) {
+            const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+            pop += cell_begin(ci, row + x1) - cell_begin(ci, row + x0);
         }
-        uint32_t pop = 0, blk = 0;
-        for (int z = lo[2]; z <= hi[2]; z++)
-            for (int y = lo[1]; y <= hi[1]; y++) {
-                const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
-                blk += cell_start[row + hi[0] + 1] - cell_start[row + lo[0]];
-                if (z >= t0[2] && z <= t1[2] && y >= t0[1] && y <= t1[1])
-                    pop += cell_start[row + t1[0] + 1] - cell_start[row + t0[0]];
-            }
-        const float eff = blk > (uint32_t)CAND_CAP_MAX ? 0.f : (float)pop / (64.f * (float)((pop + 63) / 64));
-        atomicAdd(&acc[sh * 4 + 0], eff);
-        atomicAdd(&acc[sh * 4 + 1], (float)blk);
-        atomicAdd(&acc[sh * 4 + 2], (float)blk * (float)blk);
-    }
+    flags[t] = pop ? 1 : 0;
+}
+
+// ids of the non-empty tiles of a dense-table grid whose box is mostly empty
+int build_tile_list_dense(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
+    const int ntx = (g->gp.dim[0] + g->tile[0] - 1) / g->tile[0], nty = (g->gp.dim[1] + g->tile[1] - 1) / g->tile[1],
+              ntz = (g->gp.dim[2] + g->tile[2] - 1) / g->tile[2];
+    const int64_t nt = (int64_t)ntx * nty * ntz;
+    if (nt > 0x7fffffff) return PC_OK;
+    Scratch flags(ctx, (size_t)nt);
+    g->tile_list = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(std::min<int64_t>(nt, g->n), 1));
+    if (!flags.ok() || !g->tile_list) return pc_fail(ctx, PC_NOMEM, "tile list");
+    hipLaunchKernelGGL(k_tile_nonempty, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, g->gp, g->index(), g->tile[0],
+                       g->tile[1], g->tile[2], ntx, nty, nt, flags.as<uint8_t>());
+    int64_t nocc = 0;
+    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), nt, reinterpret_cast<int32_t *>(g->tile_list), &nocc, st));
+    g->tile_count = nocc;
+    return PC_OK;
 }
 
 // chooses g->tile / g->tile_cap (once per grid)
 int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     if (g->tile[0] > 0) return PC_OK;
     const double occ = (double)g->n / (double)std::max<int64_t>(1, g->ncell);
-    const bool dense = g->occupied == 0 || (double)g->occupied > 0.85 * (double)g->ncell;
+    const bool dense = !g->uneven;
     int best[3] = {1, 1, 1};
     double expect;
     if (dense) {
@@ -469,35 +559,43 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         }
         expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2) * 1.6;
     } else {
-        const int nsample = (int)std::min<int64_t>(8192, g->n);
-        Scratch acc(ctx, sizeof(float) * 4 * NSHAPE);
-        if (!acc.ok()) return pc_fail(ctx, PC_NOMEM, "tile probe");
-        PC_HIP(hipMemsetAsync(acc.p, 0, sizeof(float) * 4 * NSHAPE, st));
-        if (g->dtype == PC_F32)
-            hipLaunchKernelGGL(k_tile_probe<Rec32>, dim3((nsample + 255) / 256), dim3(256), 0, st, g->gp,
-                               (const Rec32 *)g->rec, g->cell_start, g->n, std::max<int64_t>(1, g->n / nsample), nsample,
-                               acc.as<float>());
-        else
-            hipLaunchKernelGGL(k_tile_probe<Rec64>, dim3((nsample + 255) / 256), dim3(256), 0, st, g->gp,
-                               (const Rec64 *)g->rec, g->cell_start, g->n, std::max<int64_t>(1, g->n / nsample), nsample,
-                               acc.as<float>());
-        float *h = reinterpret_cast<float *>(ctx->pinned);
-        PC_HIP(hipMemcpyAsync(h, acc.p, sizeof(float) * 4 * NSHAPE, hipMemcpyDeviceToHost, st));
-        PC_HIP(hipStreamSynchronize(st));
-        int bi = 0;
-        for (int sh = 1; sh < NSHAPE; sh++) {
-            bool fits = true;
-            for (int a = 0; a < 3; a++) fits = fits && h_shapes[sh][a] <= std::max(1, (int)g->gp.dim[a]);
-            if (fits && h[sh * 4] > h[bi * 4] * 1.02f) bi = sh;
-        }
-        for (int a = 0; a < 3; a++) best[a] = h_shapes[bi][a];
-        const double mean = h[bi * 4 + 1] / nsample, var = std::max(0.0, h[bi * 4 + 2] / nsample - mean * mean);
-        expect = mean + 2.5 * sqrt(var);
+        // Unevenly filled box: every level of the index serves the points whose surroundings hold a
+        // handful of points per cell AT THAT LEVEL (denser ones were answered by a finer level,
+        // sparser ones wait for a coarser one).  For those a 2x2x2 tile fills most of a wave whether
+        // the points form a volume or a surface, and the block stays far below the LDS capacity.
+        // (a single cell per tile on the coarser levels: their open points sit in fuller cells)
+        for (int a = 0; a < 3; a++) best[a] = g->level > 0 ? 1 : std::min(2, std::max(1, (int)g->gp.dim[a]));
+        expect = CAND_CAP_MAX;
     }
     int cap = ((int)expect + 127) / 128 * 128;
     g->tile_cap = std::min(CAND_CAP_MAX, std::max(256, cap));
     for (int a = 0; a < 3; a++) g->tile[a] = best[a];
+    if (g->keys && g->n > 0)
+        PC_TRY(build_tile_list(ctx, g, st));
+    else if (g->uneven && g->n > 0)
+        PC_TRY(build_tile_list_dense(ctx, g, st));
     return PC_OK;
+}
+
+// After the multi-level passes: the points still flagged, as (sorted position at level 0, bound).
+template <typename REC>
+__global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__ rec, int64_t s_begin, int64_t s_end,
+                                                          const uint8_t *__restrict__ qflag,
+                                                          const float *__restrict__ qub, int32_t *__restrict__ list,
+                                                          float *__restrict__ ub, uint32_t *__restrict__ count,
+                                                          uint32_t cap) {
+    const int64_t s = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= s_end) return;
+    double x, y, z;
+    int32_t id;
+    RecTraits<REC>::load(rec + s, x, y, z, id);
+    if (qflag[id]) {
+        const uint32_t p = atomicAdd(count, 1u);
+        if (p < cap) {
+            list[p] = (int32_t)s;
+            ub[p] = qub[id];
+        }
+    }
 }
 
 template <typename REC, int KS>
@@ -533,20 +631,25 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     *handled = false;
     if (A.queries != nullptr || A.k > 32 || mode == M_COUNT || A.nq <= 0) return PC_OK;
     if (getenv("PC_AMD_EXACT_SCAN_ONLY")) return PC_OK;  // A/B switch: one-query-per-lane fp64 scan only
-    PC_TRY(choose_tile(ctx, g, st));
-    const int *tile = g->tile;
-    int64_t nt = 1;
-    for (int a = 0; a < 3; a++) {
-        A.tile[a] = tile[a];
-        A.ntile[a] = (g->gp.dim[a] + tile[a] - 1) / tile[a];
-        nt *= A.ntile[a];
+    // the levels of the index, finest first; every level gets a tile pass, a coarser one answering
+    // only what the finer ones flagged
+    const pc_grid *lv[MAX_LEVELS];
+    int nlv = 0;
+    for (const pc_grid *l = g; l && nlv < MAX_LEVELS; l = l->coarse) lv[nlv++] = l;
+    for (int i = 0; i < nlv; i++) {
+        PC_TRY(choose_tile(ctx, lv[i], st));
+        int64_t nt = 1;
+        for (int a = 0; a < 3; a++) nt *= (lv[i]->gp.dim[a] + lv[i]->tile[a] - 1) / lv[i]->tile[a];
+        if (lv[i]->tile_list) nt = lv[i]->tile_count;
+        if (nt > 0x7fffffff) return PC_OK;
     }
-    if (nt > 0x7fffffff) return PC_OK;
     A.s_end = A.s_begin + A.nq;
     A.flag_cap = (uint32_t)A.nq;
-    // [counts (256 B)] [list 1] [upper bounds 1] [list 2]; the block returns to the pool when this
-    // function ends, which is safe because everything that touches it is ordered on `st`
-    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256);
+    // [counts (256 B)] [list 1] [upper bounds 1] [list 2] [per-point bounds] [per-point flags]; the
+    // block returns to the pool when this function ends, which is safe because everything that
+    // touches it is ordered on `st`
+    const size_t npt = (size_t)g->n;
+    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (nlv > 1 ? 5 * npt + 64 : 0));
     if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run lists");
     A.flag_count = flags.as<uint32_t>();
     A.flag2_count = A.flag_count + 16;
@@ -554,16 +657,62 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     A.flag_ub = reinterpret_cast<float *>(A.flag_list + A.nq);
     A.flag2_list = A.flag_list + 2 * A.nq;
     PC_HIP(hipMemsetAsync(A.flag_count, 0, 256, st));
-    const int cap = g->tile_cap;
-    A.cand_cap = cap;
-    const size_t lds = sizeof(float4) * (size_t)cap + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
-                       sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
+    uint8_t *qflag = nullptr;
+    if (nlv > 1) {
+        A.qub_arr = reinterpret_cast<float *>(A.flag2_list + A.nq);
+        qflag = reinterpret_cast<uint8_t *>(A.qub_arr + npt);
+        PC_HIP(hipMemsetAsync(qflag, 0, npt, st));
+    }
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
-    if (g->dtype == PC_F32)
-        launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, lds, st, A);
-    else
-        launch_tile_ks<Rec64>(ks, mode, (unsigned)nt, lds, st, A);
-    PC_HIP(hipGetLastError());
+    for (int i = 0; i < nlv; i++) {
+        const pc_grid *l = lv[i];
+        A.gp = l->gp;
+        A.rec = l->rec;
+        A.ci = l->index();
+        int64_t nt = 1;
+        for (int a = 0; a < 3; a++) {
+            A.tile[a] = l->tile[a];
+            A.ntile[a] = (l->gp.dim[a] + l->tile[a] - 1) / l->tile[a];
+            nt *= A.ntile[a];
+        }
+        A.tile_list = l->tile_list;
+        if (l->tile_list) nt = l->tile_count;
+        A.cand_cap = l->tile_cap;
+        A.qflag_in = i == 0 ? nullptr : qflag;
+        A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
+        if (nt <= 0) continue;
+        const size_t lds = sizeof(float4) * (size_t)A.cand_cap + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+                           sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
+        if (g->dtype == PC_F32)
+            launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, lds, st, A);
+        else
+            launch_tile_ks<Rec64>(ks, mode, (unsigned)nt, lds, st, A);
+        PC_HIP(hipGetLastError());
+        if (qflag) {
+            // how many points are still open decides whether another (coarser) pass is worth it
+            int64_t open = 0;
+            PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
+            if (getenv("PC_AMD_DEBUG"))
+                fprintf(stderr, "[pc_amd]   level %d: cell %.4g dims %dx%dx%d tile %dx%dx%d cap %d tiles %lld sparse %d -> open %lld\n",
+                        i, l->gp.cell, l->gp.dim[0], l->gp.dim[1], l->gp.dim[2], l->tile[0], l->tile[1], l->tile[2],
+                        l->tile_cap, (long long)nt, l->keys != nullptr, (long long)open);
+            if (open < std::max<int64_t>(2048, A.nq / 200)) break;
+        }
+    }
+    if (qflag) {
+        // back to level 0: the re-run lists hold level-0 sorted positions
+        A.gp = g->gp;
+        A.rec = g->rec;
+        A.ci = g->index();
+        const unsigned nb = (unsigned)((A.nq + 255) / 256);
+        if (g->dtype == PC_F32)
+            hipLaunchKernelGGL(k_collect_flagged<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)g->rec, A.s_begin,
+                               A.s_end, qflag, A.qub_arr, A.flag_list, A.flag_ub, A.flag_count, A.flag_cap);
+        else
+            hipLaunchKernelGGL(k_collect_flagged<Rec64>, dim3(nb), dim3(256), 0, st, (const Rec64 *)g->rec, A.s_begin,
+                               A.s_end, qflag, A.qub_arr, A.flag_list, A.flag_ub, A.flag_count, A.flag_cap);
+        PC_HIP(hipGetLastError());
+    }
     // second stage: one wave per uncertified query (device-side count, no host round trip) ...
     A.qlist = A.flag_list;
     A.qub = A.flag_ub;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             // ---- the block: ring R around the query's cell at level lvl -----------------------------
             const GridParams gp = A.lv[lvl].gp;
             const REC *rec = reinterpret_cast<const REC *>(A.lv[lvl].rec);
-            const uint32_t *cell_start = A.lv[lvl].cell_start;
+            const CellIndex ci = A.lv[lvl].ci;
             const bool last_level = lvl == A.nlv - 1;
             int lo[3], hi[3];
             bool whole = true;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             uint32_t total = 0;
             for (int r = lane; r < nrows; r += PC_WAVE) {
                 const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
-                total += cell_start[row + hi[0] + 1] - cell_start[row + lo[0]];
+                total += cell_begin(ci, row + hi[0] + 1) - cell_begin(ci, row + lo[0]);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
@@ -81,7 +81,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 uint32_t m = 0;
                 for (int r = 0; r < nrows; r++) {
                     const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
-                    const uint32_t jb = cell_start[row + lo[0]], je = cell_start[row + hi[0] + 1];
+                    // sparse index: lanes 0 and 1 search, the wave shares the two results
+                    uint32_t jv = 0;
+                    if (lane < 2) jv = cell_begin(ci, lane == 0 ? row + lo[0] : row + hi[0] + 1);
+                    const uint32_t jb = __builtin_amdgcn_readfirstlane(__shfl(jv, 0, 64)),
+                                   je = __builtin_amdgcn_readfirstlane(__shfl(jv, 1, 64));
                     for (uint32_t j0 = jb; j0 < je; j0 += PC_WAVE) {
                         const uint32_t j = j0 + lane;
                         bool keep = false;
@@ -191,9 +195,9 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 }
                 if (cnt == k) ub = fmin(ub, kth);
             }
-            // widen: rings 1 and 2 at each level in turn (block edges 3, 5 | 12, 20 | 48, 80 ... fine
-            // cells), then ever larger rings at the coarsest level
-            if (!last_level && R >= 2) {
+            // widen: ring 1 at each level in turn (block edges 3, 6, 12, ... fine cells), then ever
+            // larger rings at the coarsest level
+            if (!last_level) {
                 lvl++;
                 R = 1;
             } else {
@@ -230,7 +234,7 @@ int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs
     for (const pc_grid *l = g; l && A.nlv < MAX_LEVELS; l = l->coarse) {
         A.lv[A.nlv].gp = l->gp;
         A.lv[A.nlv].rec = l->rec;
-        A.lv[A.nlv].cell_start = l->cell_start;
+        A.lv[A.nlv].ci = l->index();
         A.nlv++;
     }
     const unsigned nb = 8192;  // persistent waves; each strides over the list
