@@ -1,0 +1,73 @@
+"""The shapes of the BASELINE configurations 2-5 at sizes the CPU oracle answers in seconds,
+through the C ABI, bit-exact against the oracle (indices, counts, fp64 distances, masks, voxel
+ids) and within 1e-6 on normals (north_star asks 1e-4 rad)."""
+import numpy as np
+import pytest
+
+import datasets as D
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_lidar_frame_voxel_then_normals(hip, oracle):
+    """One 120 k-point LiDAR-like frame: voxel 0.1 m, then normals with 30 neighbours."""
+    p = D.lidar_frame(4)
+    vp, _, _ = hip.voxel_downsample(p, None, None, 0.1, {})
+    rvp, _, _ = oracle.voxel_downsample(p, 0.1)
+    assert np.array_equal(vp, rvp) and 20000 < len(vp) < len(p)
+    n = hip.normals(vp, 30, -1.0, None, {})
+    rn = oracle.normals(vp, 30)
+    assert np.abs(n - rn).max() < 1e-6
+
+
+def test_config4_terrestrial_voxel_knn32_sor(hip, oracle):
+    """Planar patches + clutter: voxel 0.05 m, kNN k = 32, statistical outlier removal."""
+    p = D.planar_patches(400_000, 5, extent=60.0, n_patches=12)
+    vp, _, _ = hip.voxel_downsample(p, None, None, 0.05, {})
+    rvp, _, _ = oracle.voxel_downsample(p, 0.05)
+    assert np.array_equal(vp, rvp)
+    cache = {}
+    idx, d2, cnt = hip.knn(vp, None, 32, -1.0, cache)
+    g = oracle.Grid(vp)
+    ridx, rd2, rcnt = g.knn_self(32)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+    kept = hip.sor(vp, 32, 2.0, cache)
+    avg = np.sqrt(rd2).sum(1) / 32.0
+    mask, _ = oracle.sor_threshold(avg, 2.0)
+    assert np.array_equal(kept, np.nonzero(mask)[0])
+
+
+def test_config5_icp_correspondences_k1(hip, oracle):
+    """Nearest-neighbour correspondences between two clouds under a sequence of rigid
+    perturbations (the reference has no ICP solver; the transforms are scripted)."""
+    target = D.torus(200_000, 6)
+    rng = np.random.default_rng(7)
+    source = target[rng.choice(len(target), 60_000, replace=False)] + rng.standard_normal((60_000, 3)) * 0.001
+    cache = {}
+    g = oracle.Grid(target, target=2.0)
+    for it in range(3):
+        a = 0.05 / (it + 1)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        q = (source @ R.T + np.array([0.01, -0.005, 0.002]) / (it + 1)).astype(np.float32).astype(np.float64)
+        idx, d2, cnt = hip.knn(target, q, 1, -1.0, cache)
+        ridx, rd2, rcnt = g.knn(q, 1)
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and (cnt == 1).all()
+
+
+def test_uneven_density_clusters(hip, oracle):
+    """Density varying by orders of magnitude: every level of the index and the re-run kernels."""
+    p = D.gaussian_clusters(300_000, 8)
+    idx, d2, cnt, avg, nrm = hip.knn_fused(p, 16, -1.0, {})
+    g = oracle.Grid(p)
+    ridx, rd2, rcnt = g.knn_self(16)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+    np.testing.assert_allclose(avg, np.sqrt(rd2).sum(1) / 16.0, rtol=1e-13)
+
+
+def test_scan_paths_agree(hip, oracle, monkeypatch):
+    """The one-query-per-lane fp64 scan alone gives the same answer as the tile path."""
+    p = D.bumpy_sphere(50_000, 9)
+    a = hip.knn(p, None, 20, -1.0, {})
+    monkeypatch.setenv("PC_AMD_EXACT_SCAN_ONLY", "1")
+    b = hip.knn(p, None, 20, -1.0, {})
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
