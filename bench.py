@@ -126,6 +126,16 @@ def main() -> int:
         elapsed = float(t.item())
 
     knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # HBM-side bytes of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
+    # collected with rocprofv3 in separate runs of this same command; they cannot be read in-process)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if n == 10_000_000 and k == 16:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except OSError:
+        pass
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n / (elapsed / args.steps)
     alg = knn_algorithmic_bytes(n, n, k)
@@ -153,12 +163,12 @@ def main() -> int:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_scan<Rec32,float,M_KNN>",
+            "kernel": "k_tile_scan<Rec32,18,M_KNN> (+ k_wave_query / k_scan re-runs of uncertified queries)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": alg,
             "kernel_ms": knn_ms,
             "kernel_queries_per_s": n / (knn_ms * 1e-3),

@@ -94,7 +94,15 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     const int k = A.k;
 
     // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
-    int64_t t = A.tile_list ? (int64_t)A.tile_list[blockIdx.x] : (int64_t)blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Remap so
+    // that each XCD walks one contiguous eighth of the tile sequence: x/y-neighbouring tiles, whose
+    // halos overlap, then hit the same L2 (placement is a speed matter only, never correctness).
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = bid & 7u;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid;
     const int tx = (int)(t % A.ntile[0]);
     t /= A.ntile[0];
     const int ty = (int)(t % A.ntile[1]);
