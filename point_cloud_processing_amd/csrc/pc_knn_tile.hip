@@ -27,6 +27,7 @@ constexpr int ORD_BITS = 10;
 constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may stage (16 KiB of LDS)
 constexpr uint32_t ORD_MASK = CAND_CAP_MAX - 1;
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int MAX_ROWS = 64;  // (tile_y + 2) * (tile_z + 2) must fit one wave
 constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most
 
@@ -83,8 +84,12 @@ struct TileRec<Rec64> {
 template <typename REC, int KS, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *cand = reinterpret_cast<float4 *>(smem);                                               // [cand_cap]
-    uint32_t *row_src = reinterpret_cast<uint32_t *>(smem + sizeof(float4) * A.cand_cap);          // [64] begin
+    // candidate block: xyz packed at a 12-byte stride (+ two pad slots) and the 4th word apart.  The
+    // pair (j, j+1) of one coordinate is then ONE ds_read2_b32 at immediate offsets (0,3), (1,4),
+    // (2,5) from a single address and lands as a register pair for packed fp32 math.
+    const int cstride = A.cand_cap + 2;
+    float *cxyz = reinterpret_cast<float *>(smem), *cws = cxyz + 3 * cstride;
+    uint32_t *row_src = reinterpret_cast<uint32_t *>(cws + cstride);                               // [64] begin
     uint32_t *row_off = row_src + MAX_ROWS;                                                        // [65] offsets
     uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_off + MAX_ROWS + 4);                     // [64][MAX_NX+1]
     uint16_t *ordbuf = cell_off + MAX_ROWS * (MAX_NX + 1);                                         // [k][64]
@@ -211,7 +216,12 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const uint32_t i = base + b * PC_WAVE + lane;
-                if (i < ncand) cand[i] = v[b];
+                if (i < ncand) {
+                    cxyz[3 * i] = v[b].x;
+                    cxyz[3 * i + 1] = v[b].y;
+                    cxyz[3 * i + 2] = v[b].z;
+                    cws[i] = v[b].w;
+                }
             }
         }
     }
@@ -282,9 +292,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             }
         }
         const int i0 = max(qc[0] - 1, 0) - lo[0], i1 = min(qc[0] + 1, gp.dim[0] - 1) - lo[0] + 1;
-#define PC_KEY(a, jj)                                                                                   \
-    ((__float_as_uint(fmaf(qz - a.z, qz - a.z, fmaf(qy - a.y, qy - a.y, (qx - a.x) * (qx - a.x)))) & ~ORD_MASK) | \
-     (jj))
         // the nine (start, length) pairs and the wave-wide longest length of each, up front:
         // the nine max-reductions overlap instead of serialising in front of every segment
         uint32_t seg_pack[9];  // start | len << 16
@@ -309,25 +316,33 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) seg_max[seg] = __builtin_amdgcn_readfirstlane(seg_max[seg]);
         const uint32_t last = ncand - 1;
+        const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
             const uint32_t start = seg_pack[seg] & 0xffffu;
             const int len = (int)(seg_pack[seg] >> 16);
             const int tmax = seg_max[seg];
-            float4 n0 = cand[min(start, last)], n1 = cand[min(start + 1, last)];
+            // two candidates per step: packed fp32 (v_pk_add/mul/fma_f32), next pair prefetched
+            const float *pn = cxyz + 3 * min(start, last);
+            f32x2 nx = {pn[0], pn[3]}, ny = {pn[1], pn[4]}, nz = {pn[2], pn[5]};
 #pragma nounroll
             for (int t = 0; t < tmax; t += 2) {
-                const float4 a0 = n0, a1 = n1;
-                const uint32_t j0 = start + t, j1 = j0 + 1;
-                n0 = cand[min(j0 + 2, last)];
-                n1 = cand[min(j1 + 2, last)];
-                const uint32_t k0 = t < len ? PC_KEY(a0, j0) : KEY_EMPTY;
-                const uint32_t k1 = t + 1 < len ? PC_KEY(a1, j1) : KEY_EMPTY;
+                const f32x2 ax = nx, ay = ny, az = nz;
+                const uint32_t j0 = start + t;
+                pn = cxyz + 3 * min(j0 + 2, last);
+                nx = f32x2{pn[0], pn[3]};
+                ny = f32x2{pn[1], pn[4]};
+                nz = f32x2{pn[2], pn[5]};
+                const f32x2 dx = qx2 - ax, dy = qy2 - ay, dz = qz2 - az;
+                f32x2 d = dx * dx;
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                const uint32_t k0 = t < len ? ((__float_as_uint(d.x) & ~ORD_MASK) | j0) : KEY_EMPTY;
+                const uint32_t k1 = t + 1 < len ? ((__float_as_uint(d.y) & ~ORD_MASK) | (j0 + 1)) : KEY_EMPTY;
                 list_insert<KS>(L, k0);
                 list_insert<KS>(L, k1);
             }
         }
-#undef PC_KEY
         if (!live) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             if (L[s] != KEY_EMPTY) {
                 double cx, cy, cz;
                 int32_t cid;
-                TileRec<REC>::exact(rec, cand[od[s]], cx, cy, cz, cid);
+                TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2], cws[od[s]]), cx, cy, cz, cid);
                 const double dx = qxd - cx, dy = qyd - cy, dz = qzd - cz;
                 double d = dx * dx;
                 d += dy * dy;
@@ -438,7 +453,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
         emit_result<MODE>(A, (int64_t)qid, cnt,
                           [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
-                              TileRec<REC>::exact(rec, cand[ordbuf[s * PC_WAVE + lane]], x, y, z, nid);
+                              const uint32_t o = ordbuf[s * PC_WAVE + lane];
+                              TileRec<REC>::exact(rec, make_float4(cxyz[3 * o], cxyz[3 * o + 1], cxyz[3 * o + 2], cws[o]), x, y, z, nid);
                               const double dx = qxd - x, dy = qyd - y, dz = qzd - z;
                               d = dx * dx;
                               d += dy * dy;
@@ -689,7 +705,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
         if (nt <= 0) continue;
-        const size_t lds = sizeof(float4) * (size_t)A.cand_cap + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+        const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
                            sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
         if (g->dtype == PC_F32)
             launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, lds, st, A);
