@@ -28,8 +28,11 @@ constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may sta
 constexpr uint32_t ORD_MASK = CAND_CAP_MAX - 1;
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f32;    // 32-bit LDS addresses: no 64-bit pointer math
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 constexpr int MAX_ROWS = 64;  // (tile_y + 2) * (tile_z + 2) must fit one wave
 constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most
+constexpr int SEL_SLOTS = 8;  // parked keys per lane between two sorted insertions
 
 __device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -37,11 +40,31 @@ __device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 }
 
+// LDS reads whose pairing and issue point the compiler must not rearrange.  The values are valid only
+// after lds_wait(), which is tied to them through its operands.
+__device__ inline void lds_read_xyz_pair(uint32_t addr, f32x2 &x, f32x2 &y, f32x2 &z) {
+    asm volatile(
+        "ds_read2_b32 %0, %3 offset1:3\n\t"
+        "ds_read2_b32 %1, %3 offset0:1 offset1:4\n\t"
+        "ds_read2_b32 %2, %3 offset0:2 offset1:5"
+        : "=&v"(x), "=&v"(y), "=&v"(z)
+        : "v"(addr));
+}
+__device__ inline void lds_wait(f32x2 &x, f32x2 &y, f32x2 &z) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y), "+v"(z));
+}
+__device__ inline uint32_t lds_read_u32(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ inline void lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+
 template <int KS>
 __device__ inline void list_insert(uint32_t (&L)[KS], uint32_t key) {
 #pragma unroll
-    for (int s = KS - 1; s > 0; s--) L[s] = umed3(L[s - 1], key, L[s]);
-    L[0] = min(L[0], key);
+    for (int s = KS - 1; s > 0; s--) asm("v_med3_u32 %0, %1, %2, %0" : "+v"(L[s]) : "v"(L[s - 1]), "v"(key));
+    asm("v_min_u32 %0, %0, %1" : "+v"(L[0]) : "v"(key));
 }
 
 // How the two record types appear in the LDS candidate block.
@@ -92,7 +115,9 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     uint32_t *row_src = reinterpret_cast<uint32_t *>(cws + cstride);                               // [64] begin
     uint32_t *row_off = row_src + MAX_ROWS;                                                        // [65] offsets
     uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_off + MAX_ROWS + 4);                     // [64][MAX_NX+1]
-    uint16_t *ordbuf = cell_off + MAX_ROWS * (MAX_NX + 1);                                         // [k][64]
+    // one area of lane-private columns: parked keys during the filter, result order afterwards
+    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_off + MAX_ROWS * (MAX_NX + 1));           // [SEL_SLOTS + 1][64]
+    uint16_t *ordbuf = reinterpret_cast<uint16_t *>(selbuf);                                       // [k][64]
     const int lane = threadIdx.x;
     const GridParams &gp = A.gp;
     const REC *rec = reinterpret_cast<const REC *>(A.rec);
@@ -282,6 +307,31 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         // ---- stage 1: fp32 filter over the lane's own 3x3x3 cells --------------------------------
         // Lanes of one cell walk the same LDS range (broadcast reads); the nine (dy, dz) row
         // segments are visited in lock-step, each for the longest segment any lane has.
+        // A key can enter the list only if it is below the list's current last entry.  The lane
+        // keeps a copy `thr` of that entry and parks the keys below it in its own column of selbuf;
+        // the (expensive) sorted insertion runs over the parked keys only, when some lane's column
+        // is nearly full and once more at the end.  `thr` lags behind the list, which only lets a
+        // few keys too many through: the final list is the same KS smallest keys either way.
+        uint32_t thr = KEY_EMPTY;
+        lds_u32 *const col = (lds_u32 *)selbuf + lane;  // slot s of this lane: col[s * 64]
+        lds_u32 *wp = col;                                                 // next free slot
+        auto drain = [&]() {
+            const uint32_t have = (uint32_t)(wp - col) >> 6;
+            uint32_t ra = (uint32_t)(uintptr_t)col;
+            uint32_t nxt = lds_read_u32(ra);
+            uint32_t s = 0;
+            do {  // at least one round: a round of empty keys changes nothing
+                lds_wait(nxt);
+                const uint32_t key = s < have ? nxt : KEY_EMPTY;
+                ra += 4 * PC_WAVE;
+                nxt = lds_read_u32(ra);  // one slot ahead (the area has a spare row)
+                list_insert<KS>(L, key);
+                s++;
+            } while (__any(s < have));
+            lds_wait(nxt);
+            thr = L[KS - 1];
+            wp = col;
+        };
         int qc[3];
         {
             const double qf[3] = {qxd, qyd, qzd};
@@ -293,12 +343,16 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         }
         const int i0 = max(qc[0] - 1, 0) - lo[0], i1 = min(qc[0] + 1, gp.dim[0] - 1) - lo[0] + 1;
         // the nine (start, length) pairs and the wave-wide longest length of each, up front:
-        // the nine max-reductions overlap instead of serialising in front of every segment
+        // the nine max-reductions overlap instead of serialising in front of every segment.
+        // Order: the query's own row, the four rows sharing a face with it, the four diagonal ones,
+        // so that the threshold tightens early.
+        constexpr int SEG_DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        constexpr int SEG_DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
         uint32_t seg_pack[9];  // start | len << 16
         int seg_max[9];
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
-            const int y = qc[1] + seg % 3 - 1, z = qc[2] + seg / 3 - 1;
+            const int y = qc[1] + SEG_DY[seg], z = qc[2] + SEG_DZ[seg];
             uint32_t st = 0, ln = 0;
             if (live && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2]) {
                 const int r = (y - lo[1]) + nry * (z - lo[2]);
@@ -315,34 +369,47 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         }
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) seg_max[seg] = __builtin_amdgcn_readfirstlane(seg_max[seg]);
-        const uint32_t last = ncand - 1;
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        const uint32_t cand_a = (uint32_t)(uintptr_t)(const lds_f32 *)cxyz;  // LDS byte address
+        const uint32_t pa_last = cand_a + 12u * (ncand - 1);
+        lds_u32 *const wp_full = col + (SEL_SLOTS - 1) * PC_WAVE;
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
             const uint32_t start = seg_pack[seg] & 0xffffu;
-            const int len = (int)(seg_pack[seg] >> 16);
+            const uint32_t end = start + (seg_pack[seg] >> 16);
             const int tmax = seg_max[seg];
-            // two candidates per step: packed fp32 (v_pk_add/mul/fma_f32), next pair prefetched
-            const float *pn = cxyz + 3 * min(start, last);
-            f32x2 nx = {pn[0], pn[3]}, ny = {pn[1], pn[4]}, nz = {pn[2], pn[5]};
+            // two candidates per step: one ds_read2_b32 per coordinate, packed fp32 math
+            // (v_pk_add/mul/fma_f32); the next pair is requested as soon as this one is consumed
+            uint32_t pa = min(cand_a + 12u * start, pa_last);
+            f32x2 nx, ny, nz;
+            lds_read_xyz_pair(pa, nx, ny, nz);
+            uint32_t j0 = start, j1 = start + 1;
 #pragma nounroll
             for (int t = 0; t < tmax; t += 2) {
-                const f32x2 ax = nx, ay = ny, az = nz;
-                const uint32_t j0 = start + t;
-                pn = cxyz + 3 * min(j0 + 2, last);
-                nx = f32x2{pn[0], pn[3]};
-                ny = f32x2{pn[1], pn[4]};
-                nz = f32x2{pn[2], pn[5]};
-                const f32x2 dx = qx2 - ax, dy = qy2 - ay, dz = qz2 - az;
+                lds_wait(nx, ny, nz);
+                const f32x2 dx = qx2 - nx, dy = qy2 - ny, dz = qz2 - nz;
+                pa = min(pa + 24u, pa_last);
+                lds_read_xyz_pair(pa, nx, ny, nz);
                 f32x2 d = dx * dx;
                 d = __builtin_elementwise_fma(dy, dy, d);
                 d = __builtin_elementwise_fma(dz, dz, d);
-                const uint32_t k0 = t < len ? ((__float_as_uint(d.x) & ~ORD_MASK) | j0) : KEY_EMPTY;
-                const uint32_t k1 = t + 1 < len ? ((__float_as_uint(d.y) & ~ORD_MASK) | (j0 + 1)) : KEY_EMPTY;
-                list_insert<KS>(L, k0);
-                list_insert<KS>(L, k1);
+                const uint32_t k0 = (__float_as_uint(d.x) & ~ORD_MASK) | j0;
+                const uint32_t k1 = (__float_as_uint(d.y) & ~ORD_MASK) | j1;
+                if (j0 < end && k0 < thr) {
+                    *wp = k0;
+                    wp += PC_WAVE;
+                }
+                if (j1 < end && k1 < thr) {
+                    *wp = k1;
+                    wp += PC_WAVE;
+                }
+                j0 += 2;
+                j1 += 2;
+                if (__any(wp >= wp_full)) drain();
             }
+            lds_wait(nx, ny, nz);  // retire the last (unused) request
         }
+        drain();
         if (!live) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
@@ -379,14 +446,12 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         }
 
         double dd[KS];
-        int32_t id[KS];
         uint32_t od[KS];
         int nsafe = 0, cnt = 0, nvalid = 0;
         double dmax = 0.0;  // farthest listed candidate: bounds the k-th distance when k are listed
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             dd[s] = INFINITY;
-            id[s] = 0x7fffffff;
             od[s] = L[s] & ORD_MASK;
             if (L[s] != KEY_EMPTY) {
                 double cx, cy, cz;
@@ -402,7 +467,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
                     nsafe++;
                     if (!(r2lim >= 0.0 && !(d < r2lim))) {
                         dd[s] = d;
-                        id[s] = cid;
                         cnt++;
                     }
                 }
@@ -427,20 +491,25 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
         if (A.qflag_in && A.qflag_out) A.qflag_out[qid] = 0;  // answered: later passes skip it
         // The list is already ordered by the truncated fp32 key, so the exact (d2, index) order
         // differs from it by a few adjacent transpositions at most: bubble passes until no lane of
-        // the wave swaps (excluded entries carry d2 = +inf and sink to the end).
+        // the wave swaps (excluded entries carry d2 = +inf and sink to the end).  Original indices
+        // matter only between equal distances and are fetched then (keeps 18 registers free).
+        auto orig_index = [&](uint32_t o) {
+            double x, y, z;
+            int32_t nid;
+            TileRec<REC>::exact(rec, make_float4(0.f, 0.f, 0.f, cws[o]), x, y, z, nid);
+            return nid;
+        };
 #pragma nounroll
         for (int pass = 0; pass < KS; pass++) {
             bool swapped = false;
 #pragma unroll
             for (int s = 0; s + 1 < KS; s++) {
                 const double da = dd[s], db = dd[s + 1];
-                const int32_t ia = id[s], ib = id[s + 1];
                 const uint32_t oa = od[s], ob = od[s + 1];
-                const bool gt = da > db || (da == db && ia > ib);
+                bool gt = da > db;
+                if (da == db && da != INFINITY) gt = orig_index(oa) > orig_index(ob);
                 dd[s] = gt ? db : da;
                 dd[s + 1] = gt ? da : db;
-                id[s] = gt ? ib : ia;
-                id[s + 1] = gt ? ia : ib;
                 od[s] = gt ? ob : oa;
                 od[s + 1] = gt ? oa : ob;
                 swapped |= gt;
@@ -581,7 +650,8 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
                 grew = true;
             }
         }
-        expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2) * 1.6;
+        expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2);
+        expect += 6.0 * sqrt(expect) + 8.0;  // Poisson mean + 6 sigma
     } else {
         // Unevenly filled box: every level of the index serves the points whose surroundings hold a
         // handful of points per cell AT THAT LEVEL (denser ones were answered by a finer level,
@@ -591,7 +661,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         for (int a = 0; a < 3; a++) best[a] = g->level > 0 ? 1 : std::min(2, std::max(1, (int)g->gp.dim[a]));
         expect = CAND_CAP_MAX;
     }
-    int cap = ((int)expect + 127) / 128 * 128;
+    int cap = ((int)expect + 63) / 64 * 64;
     g->tile_cap = std::min(CAND_CAP_MAX, std::max(256, cap));
     for (int a = 0; a < 3; a++) g->tile[a] = best[a];
     if (g->keys && g->n > 0)
@@ -706,7 +776,8 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
         if (nt <= 0) continue;
         const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
-                           sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) + sizeof(uint16_t) * PC_WAVE * (size_t)A.k;
+                           sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
+                           std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
         if (g->dtype == PC_F32)
             launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, lds, st, A);
         else
