@@ -99,6 +99,7 @@ struct pc_grid {
     // tile shape of the cooperative kNN kernel, chosen on first use (0: not chosen yet)
     mutable int tile[3] = {0, 0, 0};
     mutable int tile_cap = 0;
+    mutable int tile_waves = 1;  // waves per workgroup of that kernel
     mutable uint32_t *tile_list = nullptr;  // sparse form: linear ids of the occupied tiles
     mutable int64_t tile_count = 0;
     // the same cloud on a 2x coarser grid (and that one's own `coarse`): built for clouds that

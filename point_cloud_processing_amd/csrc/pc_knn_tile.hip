@@ -23,8 +23,8 @@
 
 namespace {
 
-constexpr int ORD_BITS = 10;
-constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may stage (16 KiB of LDS)
+constexpr int ORD_BITS = 11;
+constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may stage (32 KiB of LDS)
 constexpr uint32_t ORD_MASK = CAND_CAP_MAX - 1;
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -32,7 +32,9 @@ typedef __attribute__((address_space(3))) float lds_f32;    // 32-bit LDS addres
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 constexpr int MAX_ROWS = 64;  // (tile_y + 2) * (tile_z + 2) must fit one wave
 constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most
-constexpr int SEL_SLOTS = 8;  // parked keys per lane between two sorted insertions
+constexpr int MAX_TILE_WAVES = 4;  // waves of one workgroup, all working on the same staged block
+constexpr int UNEVEN_CAP = 1024;   // candidate capacity of the tiles of multi-level indexes
+constexpr int SEL_SLOTS = 16; // parked keys per lane between two sorted insertions
 
 __device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
@@ -105,7 +107,7 @@ struct TileRec<Rec64> {
 };
 
 template <typename REC, int KS, int MODE>
-__global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
+__global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // candidate block: xyz packed at a 12-byte stride (+ two pad slots) and the 4th word apart.  The
     // pair (j, j+1) of one coordinate is then ONE ds_read2_b32 at immediate offsets (0,3), (1,4),
@@ -116,9 +118,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     uint32_t *row_off = row_src + MAX_ROWS;                                                        // [65] offsets
     uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_off + MAX_ROWS + 4);                     // [64][MAX_NX+1]
     // one area of lane-private columns: parked keys during the filter, result order afterwards
-    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_off + MAX_ROWS * (MAX_NX + 1));           // [SEL_SLOTS + 1][64]
+    const int tid = threadIdx.x, lane = tid & (PC_WAVE - 1), wid = tid >> 6, nthr = blockDim.x;
+    // (one such area per wave)
+    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_off + MAX_ROWS * (MAX_NX + 1)) +
+                       wid * max(PC_WAVE * (SEL_SLOTS + 1), (PC_WAVE / 2) * A.k);           // [SEL_SLOTS + 1][64]
     uint16_t *ordbuf = reinterpret_cast<uint16_t *>(selbuf);                                       // [k][64]
-    const int lane = threadIdx.x;
     const GridParams &gp = A.gp;
     const REC *rec = reinterpret_cast<const REC *>(A.rec);
     const int k = A.k;
@@ -224,11 +228,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     __syncthreads();
     if (!overfull) {
         int r = 0;
-        for (uint32_t base = 0; base < ncand; base += 4 * PC_WAVE) {
+        for (uint32_t base = 0; base < ncand; base += 4 * nthr) {
             uint32_t src[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const uint32_t i = base + b * PC_WAVE + lane;
+                const uint32_t i = base + b * nthr + tid;
                 src[b] = 0;
                 if (i < ncand) {
                     while (r + 1 < nrows && i >= row_off[r + 1]) r++;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
             for (int b = 0; b < 4; b++) v[b] = TileRec<REC>::stage(rec, src[b], org);
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                const uint32_t i = base + b * PC_WAVE + lane;
+                const uint32_t i = base + b * nthr + tid;
                 if (i < ncand) {
                     cxyz[3 * i] = v[b].x;
                     cxyz[3 * i + 1] = v[b].y;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     }
     // block-relative offset of every cell boundary of every block row
     const int nx = hi[0] - lo[0] + 1;
-    for (int e = lane; e < nrows * (nx + 1); e += PC_WAVE) {
+    for (int e = tid; e < nrows * (nx + 1); e += nthr) {
         const int r = e / (nx + 1), i = e - r * (nx + 1);
         const int y = lo[1] + r % nry, z = lo[2] + r / nry;
         const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_tile_scan(ScanArgs A) {
     const double eps = 1e-7 * gp.cell;
     const double r2lim = A.radius2;
 
-    for (uint32_t qbase = 0; qbase < nquery; qbase += PC_WAVE) {
+    for (uint32_t qbase = wid * PC_WAVE; qbase < nquery; qbase += nthr) {  // the waves share the tile's queries
         const uint32_t qo = qbase + lane;
         const bool active = qo < nquery;
         // which tile row holds query ordinal qo
@@ -634,22 +638,36 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     const bool dense = !g->uneven;
     int best[3] = {1, 1, 1};
     double expect;
+    int waves = 1;
     if (dense) {
-        // the cloud fills its box: grow z, y, x in turn while the expected population fits a wave
-        const int order[3] = {2, 1, 0};
-        for (bool grew = true; grew;) {
-            grew = false;
-            for (int oi = 0; oi < 3; oi++) {
-                const int a = order[oi];
-                int t2[3] = {best[0], best[1], best[2]};
-                t2[a]++;
-                if (t2[a] > g->gp.dim[a]) continue;
-                if ((t2[1] + 2) * (t2[2] + 2) > MAX_ROWS || t2[0] + 2 > MAX_NX) continue;
-                if ((double)t2[0] * t2[1] * t2[2] * occ > 54.0) continue;
-                best[a] = t2[a];
-                grew = true;
-            }
-        }
+        // The cloud fills its box.  A workgroup of `waves` waves shares one staged block, so a
+        // bigger tile pays less halo per query and less LDS per wave.  Take the fullest shape whose
+        // expected population (plus 1.5 sigma) still fits the workgroup's lanes; among equals the one
+        // with the smallest block.
+        waves = 2;  // measured: 2 and 4 within 1 % of each other, 1 and 3 slower
+        if (const char *e = getenv("PC_AMD_TILE_WAVES")) waves = std::min(MAX_TILE_WAVES, std::max(1, atoi(e)));
+        double best_pop = -1.0, best_block = 0.0;
+        for (int tz = 1; tz <= 6; tz++)
+            for (int ty = 1; ty <= 6; ty++)
+                for (int tx = 1; tx + 2 <= MAX_NX; tx++) {
+                    if ((ty + 2) * (tz + 2) > MAX_ROWS) continue;
+                    if (tx > std::max(1, (int)g->gp.dim[0]) || ty > std::max(1, (int)g->gp.dim[1]) ||
+                        tz > std::max(1, (int)g->gp.dim[2]))
+                        continue;
+                    const double pop = occ * tx * ty * tz, block = (double)(tx + 2) * (ty + 2) * (tz + 2);
+                    const double cand = occ * block;
+                    if (pop + 1.5 * sqrt(pop) > (double)(PC_WAVE * waves) && !(tx == 1 && ty == 1 && tz == 1)) continue;
+                    if (cand + 6.0 * sqrt(cand) + 8.0 > (double)CAND_CAP_MAX && !(tx == 1 && ty == 1 && tz == 1)) continue;
+                    if (pop > best_pop * 1.0001 || (pop > best_pop * 0.9999 && block < best_block)) {
+                        best_pop = pop;
+                        best_block = block;
+                        best[0] = tx;
+                        best[1] = ty;
+                        best[2] = tz;
+                    }
+                }
+        // no more waves than the expected population needs
+        waves = std::min(waves, std::max(1, (int)ceil((best_pop + 1.5 * sqrt(std::max(best_pop, 0.0))) / PC_WAVE)));
         expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2);
         expect += 6.0 * sqrt(expect) + 8.0;  // Poisson mean + 6 sigma
     } else {
@@ -659,11 +677,12 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         // the points form a volume or a surface, and the block stays far below the LDS capacity.
         // (a single cell per tile on the coarser levels: their open points sit in fuller cells)
         for (int a = 0; a < 3; a++) best[a] = g->level > 0 ? 1 : std::min(2, std::max(1, (int)g->gp.dim[a]));
-        expect = CAND_CAP_MAX;
+        expect = UNEVEN_CAP;
     }
     int cap = ((int)expect + 63) / 64 * 64;
     g->tile_cap = std::min(CAND_CAP_MAX, std::max(256, cap));
     for (int a = 0; a < 3; a++) g->tile[a] = best[a];
+    g->tile_waves = waves;
     if (g->keys && g->n > 0)
         PC_TRY(build_tile_list(ctx, g, st));
     else if (g->uneven && g->n > 0)
@@ -693,29 +712,29 @@ __global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__
 }
 
 template <typename REC, int KS>
-void launch_tile(int mode, unsigned nblocks, size_t lds, hipStream_t st, const ScanArgs &A) {
+void launch_tile(int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
     switch (mode) {
-        case M_KNN: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_KNN>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
-        case M_SOR: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_SOR>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
+        case M_KNN: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_KNN>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A); break;
+        case M_SOR: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_SOR>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A); break;
         case M_NORMALS:
-            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NORMALS>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
+            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NORMALS>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A);
             break;
         case M_NNDIST:
-            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NNDIST>), dim3(nblocks), dim3(PC_WAVE), lds, st, A);
+            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NNDIST>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A);
             break;
-        case M_ALL: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_ALL>), dim3(nblocks), dim3(PC_WAVE), lds, st, A); break;
+        case M_ALL: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_ALL>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A); break;
         default: break;
     }
 }
 
 template <typename REC>
-void launch_tile_ks(int ks, int mode, unsigned nblocks, size_t lds, hipStream_t st, const ScanArgs &A) {
+void launch_tile_ks(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
     switch (ks) {
-        case 4: launch_tile<REC, 4>(mode, nblocks, lds, st, A); break;
-        case 10: launch_tile<REC, 10>(mode, nblocks, lds, st, A); break;
-        case 18: launch_tile<REC, 18>(mode, nblocks, lds, st, A); break;
-        case 22: launch_tile<REC, 22>(mode, nblocks, lds, st, A); break;
-        default: launch_tile<REC, 34>(mode, nblocks, lds, st, A); break;
+        case 4: launch_tile<REC, 4>(mode, nblocks, nw, lds, st, A); break;
+        case 10: launch_tile<REC, 10>(mode, nblocks, nw, lds, st, A); break;
+        case 18: launch_tile<REC, 18>(mode, nblocks, nw, lds, st, A); break;
+        case 22: launch_tile<REC, 22>(mode, nblocks, nw, lds, st, A); break;
+        default: launch_tile<REC, 34>(mode, nblocks, nw, lds, st, A); break;
     }
 }
 
@@ -775,13 +794,17 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
         if (nt <= 0) continue;
+        const int nw = std::max(1, l->tile_waves);
+        if (getenv("PC_AMD_DEBUG"))
+            fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],
+                    l->tile[2], l->tile_cap, nw, (long long)nt);
         const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
                            sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
-                           std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
+                           nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
         if (g->dtype == PC_F32)
-            launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, lds, st, A);
+            launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, nw, lds, st, A);
         else
-            launch_tile_ks<Rec64>(ks, mode, (unsigned)nt, lds, st, A);
+            launch_tile_ks<Rec64>(ks, mode, (unsigned)nt, nw, lds, st, A);
         PC_HIP(hipGetLastError());
         if (qflag) {
             // how many points are still open decides whether another (coarser) pass is worth it
