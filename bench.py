@@ -44,9 +44,11 @@ def cpu_baseline(points: np.ndarray, k: int, sample: int):
     t0 = time.perf_counter()
     g = O.Grid(points, target=4.0)
     t_build = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    g.knn_self(k, 0, sample, want_d2=True)
-    t_query = time.perf_counter() - t0
+    t_query = float("inf")
+    for _ in range(3):  # best of three: the first pass also pages the arrays in
+        t0 = time.perf_counter()
+        g.knn_self(k, 0, sample, want_d2=True)
+        t_query = min(t_query, time.perf_counter() - t0)
     value = sample / (t_build * (sample / n) + t_query)
     return {
         "value": value,
@@ -54,7 +56,7 @@ def cpu_baseline(points: np.ndarray, k: int, sample: int):
         "cores": O.num_threads(),
         "kind": "port",
         "sample": f"first {sample} of {n} cell-ordered self-queries, k={k}, against the full {n}-point grid; "
-                  f"grid build {t_build:.2f}s charged pro rata, query {t_query:.2f}s",
+                  f"grid build {t_build:.2f}s charged pro rata, query {t_query:.2f}s (best of 3 passes)",
     }
 
 
@@ -67,7 +69,7 @@ def main() -> int:
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the kNN+SOR+normals pipeline leg")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     args = ap.parse_args()
 
     import torch

@@ -36,12 +36,6 @@ constexpr int MAX_TILE_WAVES = 4;  // waves of one workgroup, all working on the
 constexpr int UNEVEN_CAP = 1024;   // candidate capacity of the tiles of multi-level indexes
 constexpr int SEL_SLOTS = 16; // parked keys per lane between two sorted insertions
 
-__device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // LDS reads whose pairing and issue point the compiler must not rearrange.  The values are valid only
 // after lds_wait(), which is tied to them through its operands.
 __device__ inline void lds_read_xyz_pair(uint32_t addr, f32x2 &x, f32x2 &y, f32x2 &z) {

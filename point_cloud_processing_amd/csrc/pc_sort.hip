@@ -27,53 +27,98 @@ __global__ __launch_bounds__(SORT_THREADS) void k_radix_hist(const K *__restrict
 }
 
 // ---- pass 3: stable scatter ---------------------------------------------------------------------
+// The block first orders its tile by digit inside LDS, then writes it out: items of one digit
+// leave as one contiguous run (coalesced stores) instead of one 4-byte store per item.
+// Stable order inside the tile = (wave, round, lane) = ascending input position: wave w owns the
+// contiguous quarter [w * 1024, (w + 1) * 1024) of the tile and ranks it on its own, so the ranking
+// loop needs no block-wide barrier.
 template <typename K>
 __global__ __launch_bounds__(SORT_THREADS) void k_radix_scatter(const K *__restrict__ keys,
                                                                  const uint32_t *__restrict__ vals, int64_t n,
                                                                  int shift, const uint32_t *__restrict__ block_off,
                                                                  int nblocks, K *__restrict__ keys_out,
                                                                  uint32_t *__restrict__ vals_out) {
-    __shared__ uint32_t run[RADIX];       // next output slot of each digit for this block
-    __shared__ uint32_t wcnt[4][RADIX];   // per-wave digit counts of the current round
+    constexpr int WAVES = SORT_THREADS / 64;
+    __shared__ K keys_s[SORT_TILE];
+    __shared__ uint32_t vals_s[SORT_TILE];
+    __shared__ uint32_t wcnt[WAVES][RADIX];  // per wave: running digit counts, then offset of the wave's run
+    __shared__ uint32_t dstart[RADIX];       // first tile-local slot of each digit
+    __shared__ uint32_t gbase[RADIX];        // global slot of the block's first item of each digit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    run[tid] = block_off[(size_t)tid * nblocks + blockIdx.x];
-    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+    for (int w = 0; w < WAVES; w++) wcnt[w][tid] = 0;
+    gbase[tid] = block_off[(size_t)tid * nblocks + blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t wbase = base + (int64_t)wave * (SORT_TILE / WAVES);
+    K key[SORT_ROUNDS];
+    uint32_t val[SORT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; r++) {  // all loads in flight before the first use
+        const int64_t i = wbase + r * 64 + lane;
+        key[r] = i < n ? keys[i] : (K)0;
+        val[r] = i < n ? vals[i] : 0u;
+    }
     __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    uint32_t rank[SORT_ROUNDS];  // rank among the wave's items of the same digit
+#pragma unroll
     for (int r = 0; r < SORT_ROUNDS; r++) {
-        int64_t i = base + (int64_t)r * SORT_THREADS + tid;
-        bool valid = i < n;
-        if (base + (int64_t)r * SORT_THREADS >= n) break;  // uniform: whole round is past the end
-        K key = valid ? keys[i] : 0;
-        uint32_t val = valid ? vals[i] : 0;
-        uint32_t d = (uint32_t)(key >> shift) & (RADIX - 1);
-        // lanes of this wave holding the same digit
-        unsigned long long m = __ballot(valid);
+        const bool valid = wbase + r * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & (RADIX - 1);
+        unsigned long long m = __ballot(valid);  // lanes of this wave holding the same digit
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            unsigned long long bal = __ballot((d >> b) & 1);
+            const unsigned long long bal = __ballot((d >> b) & 1);
             m &= ((d >> b) & 1) ? bal : ~bal;
         }
-        uint32_t rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
-        if (valid && rank_in_wave == 0) wcnt[wave][d] = __popcll(m);
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = run[d] + rank_in_wave;
-            for (int w = 0; w < wave; w++) pos += wcnt[w][d];
-            keys_out[pos] = key;
-            vals_out[pos] = val;
-        }
-        __syncthreads();
-        {
-            uint32_t add = 0;
+        const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t seen = valid ? wcnt[wave][d] : 0u;
+        rank[r] = seen + before;
+        // (wave-private row: the read above and this write are ordered by the wave's lock-step)
+        if (valid && before == 0) wcnt[wave][d] = seen + __popcll(m);
+    }
+    __syncthreads();
+    // digit totals -> tile-local start of each digit; per-wave counts -> offsets inside the digit's run
+    {
+        uint32_t tot = 0;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                add += wcnt[w][tid];
-                wcnt[w][tid] = 0;
-            }
-            run[tid] += add;
+        for (int w = 0; w < WAVES; w++) {
+            const uint32_t c = wcnt[w][tid];
+            wcnt[w][tid] = tot;
+            tot += c;
         }
+        // exclusive scan of tot over the 256 digits (one per thread)
+        uint32_t x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        __shared__ uint32_t wsum[WAVES];
+        if (lane == 63) wsum[wave] = x;
         __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        dstart[tid] = off + x - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+        if (wbase + r * 64 + lane < n) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & (RADIX - 1);
+            const uint32_t slot = dstart[d] + wcnt[wave][d] + rank[r];
+            keys_s[slot] = key[r];
+            vals_s[slot] = val[r];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - base;
+    const int count = left < SORT_TILE ? (int)left : SORT_TILE;
+#pragma unroll 4
+    for (int j = tid; j < count; j += SORT_THREADS) {
+        const K k = keys_s[j];
+        const uint32_t d = (uint32_t)(k >> shift) & (RADIX - 1);
+        const uint32_t pos = gbase[d] + ((uint32_t)j - dstart[d]);
+        keys_out[pos] = k;
+        vals_out[pos] = vals_s[j];
     }
 }
 
