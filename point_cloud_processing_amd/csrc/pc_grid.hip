@@ -229,42 +229,56 @@ __global__ __launch_bounds__(256) void k_cell_keys32(const T *__restrict__ xyz, 
     vals[i] = (uint32_t)i;
 }
 
-// Per-cell counts from the SORTED keys: the first element of every run finds the run's end
-// (a short linear probe, then a binary search) and stores the length; no atomics.
+// Per-cell counts from the SORTED keys, no searching: the last element of a run adds its end
+// position, the first subtracts its start position (u32 wrap-around cancels); two contention-free
+// atomics per occupied cell.  cnt must be zero on entry.
 __global__ __launch_bounds__(256) void k_cell_runs(const uint32_t *__restrict__ keys, int64_t n,
                                                     uint32_t *__restrict__ cnt) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t key = keys[i];
-    if (i > 0 && keys[i - 1] == key) return;
-    int64_t e = i + 1;
-    int probe = 0;
-    while (e < n && probe < 16 && keys[e] == key) {
-        e++;
-        probe++;
-    }
-    if (e < n && keys[e] == key) {  // long run: upper bound by binary search
-        int64_t lo = e, hi = n;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] <= key)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        e = lo;
-    }
-    cnt[key] = (uint32_t)(e - i);
+    const bool head = i == 0 || keys[i - 1] != key;
+    const bool tail = i + 1 == n || keys[i + 1] != key;
+    if (head && tail)
+        cnt[key] = 1u;
+    else if (tail)
+        atomicAdd(&cnt[key], (uint32_t)(i + 1));
+    else if (head)
+        atomicSub(&cnt[key], (uint32_t)i);
 }
 
-// Occupancy statistics of the sorted keys: stats[0] += sum over runs of len^2 (n times the
-// occupancy a random point sees), stats[1] += number of runs (occupied cells).
+// Occupancy statistics from the per-cell counts: stats[0] += sum of count^2 (n times the occupancy
+// a random point sees), stats[1] += number of occupied cells.
+__global__ __launch_bounds__(256) void k_count_stats(const uint32_t *__restrict__ cnt, int64_t ncell,
+                                                      unsigned long long *__restrict__ stats) {
+    unsigned long long sq = 0, runs = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long c = cnt[i];
+        sq += c * c;
+        runs += c ? 1 : 0;
+    }
+    __shared__ unsigned long long red[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sq += __shfl_down(sq, o, 64);
+        runs += __shfl_down(runs, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sq;
+        red[1][threadIdx.x >> 6] = runs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&stats[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// The same statistics straight from the sorted keys (grids too empty for a per-cell table): the
+// first element of every run finds the run's end (a short linear probe, then a binary search).
 __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ keys, int64_t n,
                                                     unsigned long long *__restrict__ stats) {
     unsigned long long sq = 0, runs = 0;
-    __shared__ unsigned long long hist[32];
-    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-    __syncthreads();
     // grid-stride: a few thousand atomics in total instead of one pair per wave
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t key = keys[i];
@@ -288,12 +302,8 @@ __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ 
             }
             sq += (unsigned long long)(e - i) * (unsigned long long)(e - i);
             runs += 1;
-            // point-weighted histogram of the run length: bin b holds lengths in [2^b, 2^(b+1))
-            atomicAdd(&hist[min(31, 63 - __clzll((unsigned long long)(e - i)))], (unsigned long long)(e - i));
         }
     }
-    __syncthreads();
-    if (threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], hist[threadIdx.x]);
     __shared__ unsigned long long red[2][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -620,7 +630,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
             break;
         }
-        bool in_tmp = false;
+        bool in_tmp = false, dense = true;
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
         for (int attempt = 0; n > 0; attempt++) {
@@ -635,31 +645,44 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
                                    (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
             rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
                                        vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
-            if (rc || !automatic || attempt >= 8) break;
+            if (rc) break;
+            const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
+            // per-cell counts (the offset table before its scan) while the table stays within 8 n + 4096
+            // cells; emptier grids keep the sorted keys instead and are searched
+            dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
+            if (g->cell_start) {
+                ctx->release(g->cell_start);
+                g->cell_start = nullptr;
+            }
+            if (dense) {
+                cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
+                g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
+                if (!g->cell_start) {
+                    rc = pc_fail(ctx, PC_NOMEM, "cell table");
+                    break;
+                }
+                if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
+                    rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell table");
+                    break;
+                }
+                hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
+            }
+            if (!automatic || attempt >= 8) break;
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
-            if (hipMemsetAsync(stats.p, 0, 34 * 8, st) != hipSuccess) break;
-            hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st,
-                               in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>(), n,
-                               stats.as<unsigned long long>());
-            if (hipMemcpyAsync(hs, stats.p, 34 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            if (hipMemsetAsync(stats.p, 0, 2 * 8, st) != hipSuccess) break;
+            if (dense)
+                hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 2048u)), dim3(256), 0, st,
+                                   g->cell_start, g->ncell, stats.as<unsigned long long>());
+            else
+                hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st, sorted_keys,
+                                   n, stats.as<unsigned long long>());
+            if (hipMemcpyAsync(hs, stats.p, 2 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) {
                 rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
                 break;
             }
             double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
-            // ... and the occupancy nine points in ten stay below (upper edge of their histogram bin):
-            // the finest level has to suit the DENSE parts, coarser levels take care of the rest
-            double p90 = 1.0;
-            unsigned long long acc = 0;
-            for (int b = 0; b < 32; b++) {
-                acc += hs[2 + b];
-                if ((double)acc >= 0.9 * (double)n) {
-                    p90 = ldexp(2.0, b);
-                    break;
-                }
-            }
-            (void)p90;
             if (seen <= 2.0 * (target + 1.0)) break;
             int32_t dim2[3];
             const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
@@ -672,32 +695,29 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         g->gp.cell = cell;
         g->gp.s = 1.0 / cell;
         g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
-        const bool dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
-        cs_bytes = dense ? sizeof(uint32_t) * (size_t)(g->ncell + 1) : sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1);
+        if (n == 0) dense = true;
+        if (!dense) cs_bytes = sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1);
         g->rec = ctx->alloc(rec_bytes);
         g->perm = (int32_t *)ctx->alloc(perm_bytes);
-        if (dense)
+        if (n == 0) {
+            cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
             g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
-        else
+        } else if (!dense) {
             g->keys = (uint32_t *)ctx->alloc(cs_bytes);
+        }
         g->bytes = rec_bytes + cs_bytes + perm_bytes;
         if (!g->rec || !g->perm || (dense ? !g->cell_start : !g->keys)) {
             rc = pc_fail(ctx, PC_NOMEM, "grid buffers");
             break;
         }
         if (n == 0) {
-            if (dense && hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess)
+            if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess)
                 rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
             break;
         }
         const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
         if (dense) {
-            // cell_start = exclusive scan of the per-cell counts (run lengths of the sorted keys)
-            if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
-                rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
-                break;
-            }
-            hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
+            // cell_start = exclusive scan of the per-cell counts
             rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
             if (rc) break;
         } else if (hipMemcpyAsync(g->keys, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st) !=
