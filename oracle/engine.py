@@ -38,8 +38,9 @@ class OracleEngine:
         mask, _ = O.sor_threshold(cache[key], std_ratio)
         return np.nonzero(mask)[0]
 
-    def radius_count(self, pts, radius, cache):
-        return O.radius_count(pts, radius)
+    def radius_count(self, pts, radius, cache, cap=None):
+        cnt = O.radius_count(pts, radius)
+        return cnt if cap is None else np.minimum(cnt, int(cap))
 
     def nn_distance(self, pts, cache):
         return O.nn_distance(pts)

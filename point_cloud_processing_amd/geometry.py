@@ -262,7 +262,8 @@ class PointCloud:
                                "must be positive.")
         if len(self) == 0:
             return PointCloud(), []
-        cnt = _engine.get().radius_count(self._points, float(radius), self._cache)
+        # only count > nb_points matters: let the engine stop counting at nb_points + 1
+        cnt = _engine.get().radius_count(self._points, float(radius), self._cache, cap=int(nb_points) + 1)
         kept = np.nonzero(cnt > int(nb_points))[0]
         return self.select_by_index(kept), kept
 

@@ -290,13 +290,22 @@ class HipEngine:
                                         self.stream()), "pc_normals")
         return out.cpu().numpy()
 
-    def radius_count(self, pts, radius, cache):
-        g = self.grid(pts, cache, 8)
+    def radius_count(self, pts, radius, cache, cap=None):
+        """Neighbours with d2 < radius^2 (self included).  With `cap` the result is min(count, cap): that is
+        all remove_radius_outlier needs (count > nb_points), and it is the hybrid search
+        kNN(k = cap, radius) on the tile kernel instead of a full ball count."""
         n = len(pts)
         cnt = self.empty((n,), torch.int32)
+        if cap is not None and 1 <= int(cap) <= _lib.PC_MAX_K:
+            g = self.grid(pts, cache, int(cap))
+            self._check(self.lib.pc_knn(self.ctx, g.h, None, _lib.PC_F64, n, int(cap), float(radius), None, None,
+                                        _lib.PC_F32, _ptr(cnt), self.stream()), "pc_knn")
+            return cnt.cpu().numpy()
+        g = self.grid(pts, cache, 8)
         self._check(self.lib.pc_radius_count(self.ctx, g.h, None, _lib.PC_F64, 0, 0, n, float(radius), _ptr(cnt),
                                              self.stream()), "pc_radius_count")
-        return cnt.cpu().numpy()
+        out = cnt.cpu().numpy()
+        return out if cap is None else np.minimum(out, int(cap))
 
     def nn_distance(self, pts, cache):
         g = self.grid(pts, cache, 2)

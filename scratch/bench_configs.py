@@ -73,3 +73,60 @@ def pipeline_case(name, pts, voxel, k):
 
 if "c3" in which: pipeline_case("C3 lidar frame voxel 0.1", D.lidar_frame(4), 0.1, 30)
 if "c4" in which: pipeline_case("C4 planar 4M voxel 0.05", D.planar_patches(4_000_000, 5), 0.05, 32)
+
+def icp_case(name, n, iters=5):
+    """BASELINE config 5 shape: external queries (a moved copy of the target), k = 1, repeated"""
+    tgt = D.torus(n, 6)
+    rng = np.random.default_rng(7)
+    src = tgt[rng.permutation(n)] + rng.normal(0, 0.002, (n, 3))
+    a = 0.02
+    Rm = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    src = (src @ Rm.T + np.array([0.01, -0.005, 0.003])).astype(np.float32)
+    xyz = torch.from_numpy(tgt.astype(np.float32)).to(eng.device)
+    q = torch.from_numpy(src).to(eng.device)
+    idx = torch.empty((n, 1), dtype=torch.int32, device=eng.device)
+    d2 = torch.empty((n, 1), dtype=torch.float32, device=eng.device)
+    h = C.c_void_p()
+    eng._check(lib.pc_grid_build(ctx, _ptr(xyz), _lib.PC_F32, n, 0.0, 1, C.byref(h), eng.stream()), "grid")
+    def one():
+        eng._check(lib.pc_knn(ctx, h, _ptr(q), _lib.PC_F32, n, 1, -1.0, _ptr(idx), _ptr(d2), _lib.PC_F32, None, eng.stream()), "knn")
+    t = timed(one, iters)
+    lib.pc_grid_destroy(ctx, h)
+    print(f"{name:28s} n={n:9d} external k=1: {t:8.2f} ms per iteration  {n/(t*1e-3)/1e6:9.1f} Mq/s", flush=True)
+
+def radius_case(name, pts, mult=5.0):
+    """remove_radius_outlier shape: count within mult x median NN distance (filtering_adapter.py:72,94)"""
+    n = len(pts)
+    xyz = torch.from_numpy(pts.astype(np.float32)).to(eng.device)
+    h = C.c_void_p()
+    eng._check(lib.pc_grid_build(ctx, _ptr(xyz), _lib.PC_F32, n, 0.0, 2, C.byref(h), eng.stream()), "grid")
+    nn = torch.empty(n, dtype=torch.float64, device=eng.device)
+    def nnd():
+        eng._check(lib.pc_nn_distance(ctx, h, 0, n, _ptr(nn), eng.stream()), "nnd")
+    tn = timed(nnd)
+    r = mult * float(nn.median())
+    lib.pc_grid_destroy(ctx, h)
+    cnt = torch.empty(n, dtype=torch.int32, device=eng.device)
+    def full():
+        g = C.c_void_p()
+        eng._check(lib.pc_grid_build(ctx, _ptr(xyz), _lib.PC_F32, n, r, 0, C.byref(g), eng.stream()), "grid")
+        eng._check(lib.pc_radius_count(ctx, g, None, _lib.PC_F32, n, 0, n, r, _ptr(cnt), eng.stream()), "count")
+        lib.pc_grid_destroy(ctx, g)
+    tc = timed(full)
+    print(f"{name:28s} n={n:9d} nn-distance {tn:7.2f} ms; radius {r:.4g}: grid+count {tc:8.2f} ms, mean count {float(cnt.double().mean()):.1f}", flush=True)
+
+def filter_case(name, pts):
+    from point_cloud_processing_amd import geometry as G, _engine
+    from point_cloud_processing_amd.app.Infrastructure.filtering_adapter import filter_pcd, FilterSettings
+    _engine.set_engine(eng)
+    def run():
+        pcd = G.PointCloud(); pcd.points = G.Vector3dVector(pts.astype(np.float64))
+        out = filter_pcd(pcd, FilterSettings(debug=False, adaptive=False, radius_abs=None))
+        return len(out.points)
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); m = run(); torch.cuda.synchronize()
+    print(f"{name:28s} n={len(pts):9d} filter_pcd defaults: {(time.perf_counter()-t0)*1e3:8.2f} ms, kept {m}", flush=True)
+
+if "icp" in which: icp_case("C5 torus 2M vs 2M", 2_000_000)
+if "radius" in which: radius_case("radius count sphere 1M", D.bumpy_sphere(1_000_000, 5)); radius_case("radius count uniform 1M", D.uniform_cube(1_000_000, 2))
+if "filter" in which: filter_case("filter_pcd sphere 1M", D.bumpy_sphere(1_000_000, 5))

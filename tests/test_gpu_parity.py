@@ -189,7 +189,13 @@ def test_radius_count_and_nn_distance(hip, oracle, name):
     rnn = oracle.nn_distance(p)
     assert np.array_equal(nn, rnn)
     r = 5.0 * float(np.median(rnn))
-    assert np.array_equal(hip.radius_count(p, r, {}), oracle.radius_count(p, r))
+    full = oracle.radius_count(p, r)
+    assert np.array_equal(hip.radius_count(p, r, {}), full)
+    # capped counts (what remove_radius_outlier asks for) ride the hybrid kNN search; a radius far
+    # beyond the cells and one that excludes most neighbours both have to agree with the full count
+    for cap, rr in [(5, r), (5, 20.0 * r), (3, 0.6 * float(np.median(rnn))), (17, r)]:
+        want = np.minimum(oracle.radius_count(p, rr), cap)
+        assert np.array_equal(hip.radius_count(p, rr, {}, cap=cap), want)
 
 
 def test_radius_count_strict(hip):
