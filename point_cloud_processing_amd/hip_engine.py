@@ -302,6 +302,9 @@ class HipEngine:
                                         _lib.PC_F32, _ptr(cnt), self.stream()), "pc_knn")
             return cnt.cpu().numpy()
         g = self.grid(pts, cache, 8)
+        if float(radius) > 2.0 * g.info()["cell"]:
+            # a ball spanning many cells: one ring of radius-sized cells beats many rings of small ones
+            g = DeviceGrid(self, self.dev_points(pts, cache), n, 0, cell=float(radius))
         self._check(self.lib.pc_radius_count(self.ctx, g.h, None, _lib.PC_F64, 0, 0, n, float(radius), _ptr(cnt),
                                              self.stream()), "pc_radius_count")
         out = cnt.cpu().numpy()
