@@ -96,6 +96,7 @@ struct pc_grid {
     int64_t ncell = 0;
     size_t bytes = 0;
     int64_t occupied = 0;     // number of non-empty cells (0: not measured)
+    double seen = 0.0;        // points in the cell of a random point (point-weighted occupancy)
     // tile shape of the cooperative kNN kernel, chosen on first use (0: not chosen yet)
     mutable int tile[3] = {0, 0, 0};
     mutable int tile_cap = 0;
@@ -108,6 +109,10 @@ struct pc_grid {
     int level = 0;        // 0: finest
     bool uneven = false;  // part of a multi-level index (set on every level)
 };
+
+// pc_grid.hip
+int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
+                   hipStream_t st);
 
 // pc_sort.hip
 int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,

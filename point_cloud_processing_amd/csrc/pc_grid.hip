@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_gather_records(const T *__restrict__ xy
     r.z = xyz[3 * (size_t)j + 2];
     r.idx = (decltype(r.idx))j;
     rec[i] = r;
-    perm[i] = (int32_t)j;
+    if (perm) perm[i] = (int32_t)j;
 }
 
 __global__ __launch_bounds__(256) void k_segment_heads(const uint64_t *__restrict__ keys, int64_t n,
@@ -667,7 +667,6 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
                 }
                 hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
             }
-            if (!automatic || attempt >= 8) break;
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
             if (hipMemsetAsync(stats.p, 0, 2 * 8, st) != hipSuccess) break;
             if (dense)
@@ -683,6 +682,8 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             }
             double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
+            g->seen = seen;
+            if (!automatic || attempt >= 8) break;
             if (seen <= 2.0 * (target + 1.0)) break;
             int32_t dim2[3];
             const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
@@ -762,6 +763,40 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
     *out = g;
     return PC_OK;
 }
+
+}  // extern "C"
+
+// External queries binned into a grid: records {x, y, z, query row} in the order of the grid's cell
+// keys (ties by query row) and the sorted keys themselves.  The queries have the grid's dtype.
+int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
+                   hipStream_t st) {
+    const size_t nb = sizeof(uint32_t) * (size_t)std::max<int64_t>(nq, 1);
+    Scratch keys(ctx, nb), keys2(ctx, nb), vals(ctx, nb), vals2(ctx, nb);
+    if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok()) return pc_fail(ctx, PC_NOMEM, "query binning scratch");
+    if (nq <= 0) return PC_OK;
+    if (g->dtype == PC_F32)
+        hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(nq, 256)), dim3(256), 0, st, (const float *)q_dev, nq,
+                           g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(nq, 256)), dim3(256), 0, st, (const double *)q_dev, nq,
+                           g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+    bool in_tmp = false;
+    PC_TRY(pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(), vals2.as<uint32_t>(),
+                                 nq, bits_for((uint64_t)g->ncell - 1), st, &in_tmp));
+    const uint32_t *sk = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
+    const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
+    if (g->dtype == PC_F32)
+        hipLaunchKernelGGL((k_gather_records<float, Rec32>), dim3(blocks_for(nq, 256)), dim3(256), 0, st,
+                           (const float *)q_dev, sv, nq, (Rec32 *)qrec_out, (int32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((k_gather_records<double, Rec64>), dim3(blocks_for(nq, 256)), dim3(256), 0, st,
+                           (const double *)q_dev, sv, nq, (Rec64 *)qrec_out, (int32_t *)nullptr);
+    PC_HIP(hipGetLastError());
+    PC_HIP(hipMemcpyAsync(qkeys_out, sk, sizeof(uint32_t) * (size_t)nq, hipMemcpyDeviceToDevice, st));
+    return PC_OK;
+}
+
+extern "C" {
 
 void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
     if (!g) return;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_scan(ScanArgs A) {
         if (A.queries == nullptr) {
             int32_t id;
             const int64_t s = A.qlist ? (int64_t)A.qlist[qi] : A.s_begin + qi;
-            RecTraits<REC>::load(rec + s, qx, qy, qz, id);
+            RecTraits<REC>::load((A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec) + s, qx, qy, qz, id);
             out_row = id;
         } else {
             const TQ *q = reinterpret_cast<const TQ *>(A.queries) + 3 * (A.s_begin + qi);
@@ -288,7 +288,6 @@ int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype
                                           out_cnt_dev, stream);
     PC_HIP(hipSetDevice(ctx->device));
     ScanArgs A = base_args(grid);
-    A.queries = queries_dev;
     A.s_begin = 0;
     A.nq = nq;
     A.k = k;
@@ -297,6 +296,19 @@ int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype
     A.out_d2 = out_d2_dev;
     A.d2_f64 = d2_dtype == PC_F64;
     A.out_cnt = out_cnt_dev;
+    if (qdtype == grid->dtype && k <= 32 && nq >= 4096 && nq < INT32_MAX) {
+        // many queries of the grid's own type: bin them into the grid (cell key, radix sort, records)
+        // and let the tile kernel answer them like the grid's own points
+        const size_t rb = grid->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64);
+        Scratch qrec(ctx, rb * (size_t)nq), qkeys(ctx, sizeof(uint32_t) * (size_t)nq);
+        if (!qrec.ok() || !qkeys.ok()) return pc_fail(ctx, PC_NOMEM, "query records");
+        PC_TRY(pc_bin_queries(ctx, grid, queries_dev, nq, qrec.p, qkeys.as<uint32_t>(), (hipStream_t)stream));
+        A.qrec = qrec.p;
+        A.qraw = queries_dev;
+        A.qci = CellIndex{nullptr, qkeys.as<uint32_t>(), (uint32_t)nq};
+        return launch_scan<M_KNN>(ctx, grid, qdtype, A, (hipStream_t)stream);
+    }
+    A.queries = queries_dev;
     return launch_scan<M_KNN>(ctx, grid, qdtype, A, (hipStream_t)stream);
 }
 

@@ -34,6 +34,12 @@ struct ScanArgs {
     const void *rec;
     CellIndex ci;
     const void *queries;  // NULL: self-query over sorted positions
+    // External queries binned into the grid: records {x, y, z, query row} sorted by the grid's cell
+    // key, and those sorted keys.  NULL: the queries are the grid's own points.  Where set, "sorted
+    // position" of a query means its position in qrec, and per-query arrays are indexed by query row.
+    const void *qrec;
+    CellIndex qci;
+    const void *qraw;     // the external queries as the caller passed them (nq x 3 of the grid's dtype)
     int64_t s_begin;      // first sorted position (self) / first query row (external)
     int64_t nq;
     int k;

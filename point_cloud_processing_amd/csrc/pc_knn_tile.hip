@@ -119,6 +119,9 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
     uint16_t *ordbuf = reinterpret_cast<uint16_t *>(selbuf);                                       // [k][64]
     const GridParams &gp = A.gp;
     const REC *rec = reinterpret_cast<const REC *>(A.rec);
+    // where the queries come from: the grid's own records, or external queries binned into the grid
+    const REC *qsrc = A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec;
+    const CellIndex &qix = A.qrec ? A.qci : A.ci;
     const int k = A.k;
 
     // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
@@ -158,9 +161,9 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
         row_begin = cell_begin(A.ci, row + lo[0]);
         row_cnt = cell_begin(A.ci, row + hi[0] + 1) - row_begin;
         if (y >= c0[1] && y <= c1[1] && z >= c0[2] && z <= c1[2]) {  // a row of the tile itself
-            q_begin = cell_begin(A.ci, row + c0[0]);
-            q_cnt = cell_begin(A.ci, row + c1[0] + 1) - q_begin;
-            if (!A.qflag_in) {  // first pass: restrict to the caller's sorted-position range
+            q_begin = cell_begin(qix, row + c0[0]);
+            q_cnt = cell_begin(qix, row + c1[0] + 1) - q_begin;
+            if (!A.qflag_in && !A.qrec) {  // first pass: restrict to the caller's sorted-position range
                 const int64_t b = max((int64_t)q_begin, A.s_begin), e = min((int64_t)q_begin + q_cnt, A.s_end);
                 q_begin = (uint32_t)b;
                 q_cnt = e > b ? (uint32_t)(e - b) : 0u;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
             if (have) {
                 double x, y, z;
                 int32_t id;
-                RecTraits<REC>::load(rec + sp, x, y, z, id);
+                RecTraits<REC>::load(qsrc + sp, x, y, z, id);
                 any = any || A.qflag_in[id] != 0;
             }
         }
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
         int32_t qid = 0;
         bool live = active;  // a query this pass has to answer
         if (active) {
-            RecTraits<REC>::load(rec + spos, qxd, qyd, qzd, qid);
+            RecTraits<REC>::load(qsrc + spos, qxd, qyd, qzd, qid);
             if (A.qflag_in) live = A.qflag_in[qid] != 0;
         }
         if (!__any(live)) continue;
@@ -557,12 +560,15 @@ __global__ __launch_bounds__(256) void k_take(const uint32_t *__restrict__ src, 
 }
 
 // unique tile ids of the occupied cells, ascending (sparse grids only)
-int build_tile_list(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
-    const int64_t n = g->n;
+// Linear ids of the tiles (of g's tile shape) that hold at least one of n sorted cell keys.
+int tile_list_from_keys(pc_ctx *ctx, const pc_grid *g, const uint32_t *keys, int64_t n, hipStream_t st, uint32_t **out,
+                        int64_t *count) {
+    *out = nullptr;
+    *count = 0;
     const unsigned nb = (unsigned)((n + 255) / 256);
     Scratch flags(ctx, (size_t)n), heads(ctx, sizeof(int32_t) * (size_t)n);
     if (!flags.ok() || !heads.ok()) return pc_fail(ctx, PC_NOMEM, "tile list");
-    hipLaunchKernelGGL(k_key_heads, dim3(nb), dim3(256), 0, st, g->keys, n, flags.as<uint8_t>());
+    hipLaunchKernelGGL(k_key_heads, dim3(nb), dim3(256), 0, st, keys, n, flags.as<uint8_t>());
     int64_t u = 0;
     PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), n, heads.as<int32_t>(), &u, st));
     Scratch tid(ctx, sizeof(uint32_t) * (size_t)u), tid2(ctx, sizeof(uint32_t) * (size_t)u);
@@ -571,8 +577,8 @@ int build_tile_list(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     const int ntx = (g->gp.dim[0] + g->tile[0] - 1) / g->tile[0], nty = (g->gp.dim[1] + g->tile[1] - 1) / g->tile[1],
               ntz = (g->gp.dim[2] + g->tile[2] - 1) / g->tile[2];
     const unsigned ub = (unsigned)((u + 255) / 256);
-    hipLaunchKernelGGL(k_tile_ids, dim3(ub), dim3(256), 0, st, g->keys, heads.as<int32_t>(), u, g->gp.dim[0],
-                       g->gp.dim[1], g->tile[0], g->tile[1], g->tile[2], ntx, nty, tid.as<uint32_t>(), v.as<uint32_t>());
+    hipLaunchKernelGGL(k_tile_ids, dim3(ub), dim3(256), 0, st, keys, heads.as<int32_t>(), u, g->gp.dim[0], g->gp.dim[1],
+                       g->tile[0], g->tile[1], g->tile[2], ntx, nty, tid.as<uint32_t>(), v.as<uint32_t>());
     uint64_t nt = (uint64_t)ntx * nty * ntz;
     int bits = 1;
     while (bits < 32 && (nt >> bits)) bits++;
@@ -583,14 +589,19 @@ int build_tile_list(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     hipLaunchKernelGGL(k_key_heads, dim3(ub), dim3(256), 0, st, sorted, u, flags.as<uint8_t>());
     int64_t nocc = 0;
     PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), u, heads.as<int32_t>(), &nocc, st));
-    g->tile_list = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(nocc, 1));
-    if (!g->tile_list) return pc_fail(ctx, PC_NOMEM, "tile list");
+    uint32_t *list = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(nocc, 1));
+    if (!list) return pc_fail(ctx, PC_NOMEM, "tile list");
     hipLaunchKernelGGL(k_take, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, st, sorted, heads.as<int32_t>(), nocc,
-                       g->tile_list);
+                       list);
     PC_HIP(hipGetLastError());
     PC_HIP(hipStreamSynchronize(st));
-    g->tile_count = nocc;
+    *out = list;
+    *count = nocc;
     return PC_OK;
+}
+
+int build_tile_list(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
+    return tile_list_from_keys(ctx, g, g->keys, g->n, st, &g->tile_list, &g->tile_count);
 }
 
 __global__ __launch_bounds__(256) void k_tile_nonempty(GridParams gp, CellIndex ci, int tx, int ty, int tz, int ntx,
@@ -667,9 +678,9 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     } else {
         // Unevenly filled box: every level of the index serves the points whose surroundings hold a
         // handful of points per cell AT THAT LEVEL (denser ones were answered by a finer level,
-        // sparser ones wait for a coarser one).  For those a 2x2x2 tile fills most of a wave whether
-        // the points form a volume or a surface, and the block stays far below the LDS capacity.
-        // (a single cell per tile on the coarser levels: their open points sit in fuller cells)
+        // sparser ones wait for a coarser one).  Start from a 2x2x2 tile (a single cell on the coarser
+        // levels, whose open points sit in fuller cells) and grow it while the occupied tiles hold
+        // too few points to fill a wave (thin surfaces, scan lines); the shape is settled below.
         for (int a = 0; a < 3; a++) best[a] = g->level > 0 ? 1 : std::min(2, std::max(1, (int)g->gp.dim[a]));
         expect = UNEVEN_CAP;
     }
@@ -677,10 +688,30 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     g->tile_cap = std::min(CAND_CAP_MAX, std::max(256, cap));
     for (int a = 0; a < 3; a++) g->tile[a] = best[a];
     g->tile_waves = waves;
-    if (g->keys && g->n > 0)
-        PC_TRY(build_tile_list(ctx, g, st));
-    else if (g->uneven && g->n > 0)
-        PC_TRY(build_tile_list_dense(ctx, g, st));
+    for (int grow = 0; g->n > 0 && (g->keys || g->uneven); grow++) {
+        if (g->keys)
+            PC_TRY(build_tile_list(ctx, g, st));
+        else
+            PC_TRY(build_tile_list_dense(ctx, g, st));
+        if (!g->uneven || !g->tile_list || grow >= 3) break;
+        // grow only where the occupied cells are evenly filled (a surface of even density): the mean
+        // says nothing about a cloud whose points sit mostly in a few full tiles among many empty ones
+        const double pop = (double)g->n / (double)std::max<int64_t>(1, g->tile_count);
+        const double cell_mean = (double)g->n / (double)std::max<int64_t>(1, g->occupied);
+        if (pop >= 16.0 || g->occupied <= 0 || g->seen > 2.0 * (cell_mean + 1.0)) break;
+        int t2[3];
+        bool changed = false;
+        for (int a = 0; a < 3; a++) {
+            t2[a] = std::min(g->tile[a] + 1, std::max(1, (int)g->gp.dim[a]));
+            if (a == 0) t2[a] = std::min(t2[a], MAX_NX - 2);
+            changed |= t2[a] != g->tile[a];
+        }
+        if (!changed || (t2[1] + 2) * (t2[2] + 2) > MAX_ROWS) break;
+        ctx->release(g->tile_list);
+        g->tile_list = nullptr;
+        g->tile_count = 0;
+        for (int a = 0; a < 3; a++) g->tile[a] = t2[a];
+    }
     return PC_OK;
 }
 
@@ -755,7 +786,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // [counts (256 B)] [list 1] [upper bounds 1] [list 2] [per-point bounds] [per-point flags]; the
     // block returns to the pool when this function ends, which is safe because everything that
     // touches it is ordered on `st`
-    const size_t npt = (size_t)g->n;
+    const size_t npt = A.qrec ? (size_t)A.nq : (size_t)g->n;
     Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (nlv > 1 ? 5 * npt + 64 : 0));
     if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run lists");
     A.flag_count = flags.as<uint32_t>();
@@ -771,8 +802,19 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         PC_HIP(hipMemsetAsync(qflag, 0, npt, st));
     }
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
+    // external queries arrive binned into level 0; a coarser level bins them again into its own cells
+    const void *qrec0 = A.qrec;
+    const CellIndex qci0 = A.qci;
+    const size_t qrec_bytes = (g->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64)) * (size_t)A.nq;
+    Scratch qrec_l(ctx, A.qrec && nlv > 1 ? qrec_bytes : 0), qkeys_l(ctx, A.qrec && nlv > 1 ? sizeof(uint32_t) * (size_t)A.nq : 0);
+    if (!qrec_l.ok() || !qkeys_l.ok()) return pc_fail(ctx, PC_NOMEM, "query records");
     for (int i = 0; i < nlv; i++) {
         const pc_grid *l = lv[i];
+        if (A.qrec && i > 0) {
+            PC_TRY(pc_bin_queries(ctx, l, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+            A.qrec = qrec_l.p;
+            A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq};
+        }
         A.gp = l->gp;
         A.rec = l->rec;
         A.ci = l->index();
@@ -784,6 +826,14 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         }
         A.tile_list = l->tile_list;
         if (l->tile_list) nt = l->tile_count;
+        if (A.qrec && l->tile_list) {
+            // the grid's list names the tiles that hold POINTS; external queries need the tiles that hold
+            // queries (the block returns to the pool right away: everything using it is ordered on st)
+            uint32_t *ql = nullptr;
+            PC_TRY(tile_list_from_keys(ctx, l, A.qci.keys, (int64_t)A.qci.n, st, &ql, &nt));
+            A.tile_list = ql;
+            ctx->release(ql);
+        }
         A.cand_cap = l->tile_cap;
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
@@ -816,12 +866,15 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.gp = g->gp;
         A.rec = g->rec;
         A.ci = g->index();
+        A.qrec = qrec0;
+        A.qci = qci0;
         const unsigned nb = (unsigned)((A.nq + 255) / 256);
+        const void *qsrc = A.qrec ? A.qrec : g->rec;  // (external queries: positions in the level-0 bins)
         if (g->dtype == PC_F32)
-            hipLaunchKernelGGL(k_collect_flagged<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)g->rec, A.s_begin,
+            hipLaunchKernelGGL(k_collect_flagged<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)qsrc, A.s_begin,
                                A.s_end, qflag, A.qub_arr, A.flag_list, A.flag_ub, A.flag_count, A.flag_cap);
         else
-            hipLaunchKernelGGL(k_collect_flagged<Rec64>, dim3(nb), dim3(256), 0, st, (const Rec64 *)g->rec, A.s_begin,
+            hipLaunchKernelGGL(k_collect_flagged<Rec64>, dim3(nb), dim3(256), 0, st, (const Rec64 *)qsrc, A.s_begin,
                                A.s_end, qflag, A.qub_arr, A.flag_list, A.flag_ub, A.flag_count, A.flag_cap);
         PC_HIP(hipGetLastError());
     }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         double ub = (double)A.qub[qi];
         double qx, qy, qz;
         int32_t qid;
-        RecTraits<REC>::load(rec0 + spos, qx, qy, qz, qid);
+        RecTraits<REC>::load((A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec0) + spos, qx, qy, qz, qid);
         const double qv[3] = {qx, qy, qz};
         int cnt = 0, lvl = 0, R = 1, retries = 0;
         bool spilled = false;

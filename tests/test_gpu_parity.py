@@ -75,6 +75,33 @@ def test_knn_external_queries_inside_and_outside(hip, oracle):
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
 
 
+@pytest.mark.parametrize("name,k", [("uniform", 1), ("uniform", 8), ("sphere", 1), ("clusters", 4), ("planes", 1),
+                                    ("fp64", 3), ("lattice", 2)])
+def test_knn_many_external_queries(hip, oracle, name, k):
+    """Query sets large enough to be binned into the grid and answered by the tile kernel (the ICP shape:
+    a moved copy of the cloud), plus queries far outside the box and in empty regions."""
+    p = CLOUDS[name]()
+    rng = np.random.default_rng(77)
+    ext = p.max(0) - p.min(0)
+    moved = p[rng.permutation(len(p))] + rng.normal(0.0, 0.002, p.shape) * ext + 0.01 * ext
+    far = p.min(0) + (rng.random((600, 3)) * 3.0 - 1.0) * ext
+    q = np.concatenate([moved, far, p[:500]])  # the last block coincides with points: exact zero distances
+    if name != "fp64":
+        q = q.astype(np.float32).astype(np.float64)
+    while len(q) < 4096:  # (the lattice: shifted copies sit at equal distances from several points)
+        q = np.concatenate([q, q + 0.25])
+    idx, d2, cnt = hip.knn(p, q, k, -1.0, {})
+    ridx, rd2, rcnt = oracle.knn(p, q, k)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(d2, rd2) and np.array_equal(idx, ridx)
+    # hybrid radius on the same path
+    r = 0.02 * float(ext.max())
+    idx, d2, cnt = hip.knn(p, q, k, r, {})
+    ridx, rd2, rcnt = oracle.knn(p, q, k, r)
+    assert np.array_equal(cnt, rcnt)
+    m = np.arange(k)[None, :] < cnt[:, None]
+    assert np.array_equal(idx[m], ridx[m]) and np.array_equal(d2[m], rd2[m])
+
+
 def test_knn_hybrid_radius(hip, oracle):
     p = D.bumpy_sphere(12000, 61)
     r = 0.004
