@@ -8,6 +8,8 @@
 
 #include "pc_amd.h"
 
+constexpr int MAX_LEVELS = 8;  // resolution levels of one spatial index (pc_grid::coarse chain)
+
 #define PC_WAVE 64  // gfx950 wavefront width (hard-coded: not a host compile-time constant)
 
 struct pc_ctx {
@@ -77,11 +79,14 @@ struct GridParams {
 };
 
 // Cell key -> first sorted position of that cell.  Dense form: a table of ncell + 1 offsets.
-// Sparse form (huge, mostly empty grids): no table; the sorted per-point cell keys are searched.
+// Sparse form (huge, mostly empty grids): no table; the sorted per-point cell keys are searched,
+// inside the key's (y, z) row when a row directory exists (a handful of steps instead of log2 n).
 struct CellIndex {
-    const uint32_t *table;  // ncell + 1 entries, or NULL
-    const uint32_t *keys;   // n sorted cell keys (sparse form)
+    const uint32_t *table;      // ncell + 1 entries, or NULL
+    const uint32_t *keys;       // n sorted cell keys (sparse form)
     uint32_t n;
+    const uint32_t *row_start;  // sparse form: first sorted position of every (y, z) row, + 2 end entries; or NULL
+    uint32_t nx;                // cells per row
 };
 
 struct pc_grid {
@@ -91,7 +96,8 @@ struct pc_grid {
     void *rec = nullptr;          // Rec32[n] or Rec64[n]
     uint32_t *cell_start = nullptr;  // ncell + 1 (dense form), or NULL
     uint32_t *keys = nullptr;        // n sorted cell keys (sparse form), or NULL
-    CellIndex index() const { return CellIndex{cell_start, keys, (uint32_t)n}; }
+    uint32_t *row_start = nullptr;   // sparse form: row directory (rows + 2 entries), or NULL
+    CellIndex index() const { return CellIndex{cell_start, keys, (uint32_t)n, row_start, (uint32_t)gp.dim[0]}; }
     int32_t *perm = nullptr;      // sorted position -> original index
     int64_t ncell = 0;
     size_t bytes = 0;

@@ -247,16 +247,38 @@ __global__ __launch_bounds__(256) void k_cell_runs(const uint32_t *__restrict__ 
         atomicSub(&cnt[key], (uint32_t)i);
 }
 
+// The same for (y, z) rows of cells: cnt[row] = points of the row (row = key / nx).
+__global__ __launch_bounds__(256) void k_row_runs(const uint32_t *__restrict__ keys, int64_t n, uint32_t nx,
+                                                   uint32_t *__restrict__ cnt) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = keys[i] / nx;
+    const bool head = i == 0 || keys[i - 1] / nx != row;
+    const bool tail = i + 1 == n || keys[i + 1] / nx != row;
+    if (head && tail)
+        cnt[row] = 1u;
+    else if (tail)
+        atomicAdd(&cnt[row], (uint32_t)(i + 1));
+    else if (head)
+        atomicSub(&cnt[row], (uint32_t)i);
+}
+
 // Occupancy statistics from the per-cell counts: stats[0] += sum of count^2 (n times the occupancy
 // a random point sees), stats[1] += number of occupied cells.
 __global__ __launch_bounds__(256) void k_count_stats(const uint32_t *__restrict__ cnt, int64_t ncell,
                                                       unsigned long long *__restrict__ stats) {
     unsigned long long sq = 0, runs = 0;
+    __shared__ unsigned long long hist[32];  // points by the size class of their cell: [2^b, 2^(b+1))
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * 256) {
         const unsigned long long c = cnt[i];
         sq += c * c;
         runs += c ? 1 : 0;
+        if (c > 1) atomicAdd(&hist[63 - __clzll(c)], c);
     }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], hist[threadIdx.x]);
     __shared__ unsigned long long red[2][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -279,6 +301,9 @@ __global__ __launch_bounds__(256) void k_count_stats(const uint32_t *__restrict_
 __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ keys, int64_t n,
                                                     unsigned long long *__restrict__ stats) {
     unsigned long long sq = 0, runs = 0;
+    __shared__ unsigned long long hist[32];
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
     // grid-stride: a few thousand atomics in total instead of one pair per wave
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t key = keys[i];
@@ -302,8 +327,11 @@ __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ 
             }
             sq += (unsigned long long)(e - i) * (unsigned long long)(e - i);
             runs += 1;
+            if (e - i > 1) atomicAdd(&hist[63 - __clzll((unsigned long long)(e - i))], (unsigned long long)(e - i));
         }
     }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], hist[threadIdx.x]);
     __shared__ unsigned long long red[2][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -630,7 +658,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
             break;
         }
-        bool in_tmp = false, dense = true;
+        bool in_tmp = false, dense = true, refined = false;
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
         for (int attempt = 0; n > 0; attempt++) {
@@ -668,14 +696,14 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
                 hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
             }
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
-            if (hipMemsetAsync(stats.p, 0, 2 * 8, st) != hipSuccess) break;
+            if (hipMemsetAsync(stats.p, 0, 34 * 8, st) != hipSuccess) break;
             if (dense)
-                hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 2048u)), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 512u)), dim3(256), 0, st,
                                    g->cell_start, g->ncell, stats.as<unsigned long long>());
             else
                 hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st, sorted_keys,
                                    n, stats.as<unsigned long long>());
-            if (hipMemcpyAsync(hs, stats.p, 2 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            if (hipMemcpyAsync(hs, stats.p, 34 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) {
                 rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
                 break;
@@ -683,8 +711,35 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
             g->seen = seen;
-            if (!automatic || attempt >= 8) break;
-            if (seen <= 2.0 * (target + 1.0)) break;
+            if (getenv("PC_AMD_DEBUG") && automatic)
+                fprintf(stderr, "[pc_amd]   grid attempt %d: cell %.4g cells %lld occupied %lld seen %.1f (target %.1f)\n", attempt,
+                        cell, (long long)g->ncell, (long long)g->occupied, seen, target);
+            if (!automatic || attempt >= 8 || refined) break;
+            if (seen <= 2.0 * (target + 1.0)) {
+                // The average point is served.  Points in cells several times fuller (dense patches,
+                // cluster cores) would overflow the candidate block of the tile kernel at EVERY level
+                // (coarser cells are fuller still): if more than one point in fifty sits in such cells,
+                // make the finest level fine enough for them; the coarser levels serve the rest.
+                const double crowded = 64.0;  // ~ block capacity / cells a surface crosses in a block
+                double top = 1.0;             // upper edge of the size class holding the 98 % point
+                unsigned long long acc = 0;
+                for (int b = 31; b >= 1; b--) {  // from the fullest size class down
+                    acc += hs[2 + b];
+                    if ((double)acc > 0.02 * (double)n) {
+                        top = ldexp(2.0, b);
+                        break;
+                    }
+                }
+                if (top <= crowded || (double)hs[1] >= 0.85 * (double)g->ncell) break;
+                const int f = std::min(3, std::max(1, (int)ceil(0.5 * log2(top / 32.0))));
+                int32_t dim2[3];
+                const double got = fit_dims(cell / (double)(1 << f), dim2);
+                if (got > 0.93 * cell) break;
+                cell = got;
+                for (int a = 0; a < 3; a++) g->gp.dim[a] = dim2[a];
+                refined = true;
+                continue;
+            }
             int32_t dim2[3];
             const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
             const double got = fit_dims(want, dim2);
@@ -721,10 +776,27 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             // cell_start = exclusive scan of the per-cell counts
             rc = pc_exclusive_scan_u32(ctx, g->cell_start, g->ncell + 1, st);
             if (rc) break;
-        } else if (hipMemcpyAsync(g->keys, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st) !=
-                   hipSuccess) {
-            rc = pc_fail(ctx, PC_HIP_ERROR, "copy sorted keys");
-            break;
+        } else {
+            if (hipMemcpyAsync(g->keys, sorted_keys, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st) !=
+                hipSuccess) {
+                rc = pc_fail(ctx, PC_HIP_ERROR, "copy sorted keys");
+                break;
+            }
+            // row directory: searches for a cell then stay inside its (y, z) row
+            const int64_t nrows = (int64_t)g->gp.dim[1] * g->gp.dim[2];
+            if (nrows + 2 <= 16 * n + 65536) {
+                const size_t rb = sizeof(uint32_t) * (size_t)(nrows + 2);
+                g->row_start = (uint32_t *)ctx->alloc(rb);
+                if (!g->row_start || hipMemsetAsync(g->row_start, 0, rb, st) != hipSuccess) {
+                    rc = pc_fail(ctx, PC_NOMEM, "row directory");
+                    break;
+                }
+                hipLaunchKernelGGL(k_row_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n,
+                                   (uint32_t)g->gp.dim[0], g->row_start);
+                rc = pc_exclusive_scan_u32(ctx, g->row_start, nrows + 2, st);
+                if (rc) break;
+                g->bytes += rb;
+            }
         }
         const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
         if (dtype == PC_F32)
@@ -740,12 +812,12 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         pc_grid_destroy(ctx, g);
         return rc;
     }
-    // Unevenly filled box (surfaces, clusters, clutter): add up to five coarser levels, twice the edge
+    // Unevenly filled box (surfaces, clusters, clutter): add coarser levels, twice the edge
     // each, so that a query in a sparse region finds k neighbours within one ring of SOME level.
     if (automatic && n > 4096 && g->occupied > 0 && (double)g->occupied < 0.85 * (double)g->ncell) {
         pc_grid *fine = g;
         g->uneven = true;
-        for (int lv = 1; lv < 6; lv++) {
+        for (int lv = 1; lv < MAX_LEVELS; lv++) {
             if (std::max(fine->gp.dim[0], std::max(fine->gp.dim[1], fine->gp.dim[2])) <= 4) break;
             pc_grid *c = nullptr;
             rc = pc_grid_build(ctx, xyz_dev, dtype, n, fine->gp.cell * 2.0, k_hint, &c, stream);
@@ -805,6 +877,7 @@ void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
         if (g->rec) ctx->release(g->rec);
         if (g->cell_start) ctx->release(g->cell_start);
         if (g->keys) ctx->release(g->keys);
+        if (g->row_start) ctx->release(g->row_start);
         if (g->tile_list) ctx->release(g->tile_list);
         if (g->perm) ctx->release(g->perm);
     }

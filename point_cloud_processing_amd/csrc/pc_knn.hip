@@ -305,7 +305,7 @@ int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype
         PC_TRY(pc_bin_queries(ctx, grid, queries_dev, nq, qrec.p, qkeys.as<uint32_t>(), (hipStream_t)stream));
         A.qrec = qrec.p;
         A.qraw = queries_dev;
-        A.qci = CellIndex{nullptr, qkeys.as<uint32_t>(), (uint32_t)nq};
+        A.qci = CellIndex{nullptr, qkeys.as<uint32_t>(), (uint32_t)nq, nullptr, 0u};
         return launch_scan<M_KNN>(ctx, grid, qdtype, A, (hipStream_t)stream);
     }
     A.queries = queries_dev;

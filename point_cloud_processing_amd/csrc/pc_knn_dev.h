@@ -9,6 +9,11 @@
 __device__ inline uint32_t cell_begin(const CellIndex &ci, int64_t key) {
     if (ci.table) return ci.table[key];
     uint32_t lo = 0, hi = ci.n;
+    if (ci.row_start) {
+        const uint32_t row = (uint32_t)(key / ci.nx);
+        lo = ci.row_start[row];
+        hi = ci.row_start[row + 1];
+    }
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if ((int64_t)ci.keys[mid] < key)
@@ -27,7 +32,6 @@ struct Level {
     const void *rec;
     CellIndex ci;
 };
-constexpr int MAX_LEVELS = 6;
 
 struct ScanArgs {
     GridParams gp;

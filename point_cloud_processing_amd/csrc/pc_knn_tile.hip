@@ -813,7 +813,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         if (A.qrec && i > 0) {
             PC_TRY(pc_bin_queries(ctx, l, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
             A.qrec = qrec_l.p;
-            A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq};
+            A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq, nullptr, 0u};
         }
         A.gp = l->gp;
         A.rec = l->rec;
