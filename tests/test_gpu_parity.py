@@ -269,6 +269,19 @@ def test_large_uniform_matches_oracle(hip, oracle):
     np.testing.assert_allclose(avg, np.sqrt(rd2).sum(1) / 16.0, rtol=1e-13)
 
 
+def test_headline_10m_matches_oracle(hip, oracle):
+    """The bench workload itself (10 M uniform points, seed 3, k = 16): every row against the CPU oracle's
+    grid search, plus the size-independent properties (self first at distance 0, ascending distances)."""
+    p = D.uniform_cube(10_000_000, 3)
+    idx, d2, cnt = hip.knn(p, None, 16, -1.0, {})
+    assert (cnt == 16).all()
+    assert np.array_equal(idx[:, 0], np.arange(len(p), dtype=np.int32)) and not d2[:, 0].any()
+    assert (np.diff(d2, axis=1) >= 0).all()
+    ridx, rd2, rcnt = oracle.Grid(p).knn_self(16)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_query_shards_cover_and_agree(hip, oracle, world):
     """Each rank's slice of sorted positions, run one after the other on this GPU, reproduces the
