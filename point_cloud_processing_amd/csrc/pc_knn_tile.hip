@@ -507,15 +507,34 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
             for (int s = 0; s + 1 < KS; s++) {
                 const double da = dd[s], db = dd[s + 1];
                 const uint32_t oa = od[s], ob = od[s + 1];
-                bool gt = da > db;
-                if (da == db && da != INFINITY) gt = orig_index(oa) > orig_index(ob);
-                dd[s] = gt ? db : da;
-                dd[s + 1] = gt ? da : db;
+                const bool gt = da > db;
+                dd[s] = fmin(da, db);
+                dd[s + 1] = fmax(da, db);
                 od[s] = gt ? ob : oa;
                 od[s + 1] = gt ? oa : ob;
                 swapped |= gt;
             }
             if (!__any(swapped)) break;
+        }
+        // equal distances (rare): order those neighbours by original index
+        bool ties = false;
+#pragma unroll
+        for (int s = 0; s + 1 < KS; s++) ties |= dd[s] == dd[s + 1] && dd[s] != INFINITY;
+        if (__any(ties)) {
+#pragma nounroll
+            for (int pass = 0; pass < KS; pass++) {
+                bool swapped = false;
+#pragma unroll
+                for (int s = 0; s + 1 < KS; s++) {
+                    const uint32_t oa = od[s], ob = od[s + 1];
+                    bool gt = false;
+                    if (dd[s] == dd[s + 1] && dd[s] != INFINITY) gt = orig_index(oa) > orig_index(ob);
+                    od[s] = gt ? ob : oa;
+                    od[s + 1] = gt ? oa : ob;
+                    swapped |= gt;
+                }
+                if (!__any(swapped)) break;
+            }
         }
         cnt = min(cnt, k);
 #pragma unroll
@@ -649,7 +668,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         // bigger tile pays less halo per query and less LDS per wave.  Take the fullest shape whose
         // expected population (plus 1.5 sigma) still fits the workgroup's lanes; among equals the one
         // with the smallest block.
-        waves = 2;  // measured: 2 and 4 within 1 % of each other, 1 and 3 slower
+        waves = MAX_TILE_WAVES;  // measured at 10 M, k = 16: 4 waves 2.78 ms, 2 waves 3.27 ms (LDS-bound occupancy)
         if (const char *e = getenv("PC_AMD_TILE_WAVES")) waves = std::min(MAX_TILE_WAVES, std::max(1, atoi(e)));
         double best_pop = -1.0, best_block = 0.0;
         for (int tz = 1; tz <= 6; tz++)
