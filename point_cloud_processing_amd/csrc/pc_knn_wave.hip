@@ -30,7 +30,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         int32_t qid;
         RecTraits<REC>::load((A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec0) + spos, qx, qy, qz, qid);
         const double qv[3] = {qx, qy, qz};
-        int cnt = 0, lvl = 0, R = 1, retries = 0;
+        int cnt = 0, lvl = 0, R = 1;
         bool spilled = false;
         for (;;) {
             // ---- the block: ring R around the query's cell at level lvl -----------------------------
@@ -77,9 +77,49 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             bool certified = false;
             if (total >= (uint32_t)k || can_end_short) {
                 // ---- survivors: candidates not farther than the bound, compacted into LDS ---------------
-                const double ub_in = ub;
+                // Thinning inside LDS: the k-th smallest of ANY 64 held survivors bounds the true k-th
+                // distance, so everything farther than it can go (and later candidates are tested
+                // against that bound).  Repeated while it still removes something.
+                auto thin = [&](uint32_t mm) -> uint32_t {
+                    while (mm > 2 * PC_WAVE) {
+                        const double di = sv_d[lane];
+                        const int32_t ii = sv_id[lane];
+                        int rank = 0;
+                        for (int j = 0; j < PC_WAVE; j++) {
+                            const double dj = __shfl(di, j, 64);
+                            const int32_t ij = __shfl(ii, j, 64);
+                            rank += (dj < di || (dj == di && ij < ii)) ? 1 : 0;
+                        }
+                        const unsigned long long sel = __ballot(rank == k - 1);
+                        const double cut = __shfl(di, __ffsll((long long)sel) - 1, 64);  // k <= 64: one lane has it
+                        uint32_t kept = 0;
+                        for (uint32_t base = 0; base < mm; base += PC_WAVE) {
+                            const uint32_t i = base + lane;
+                            const bool have = i < mm;
+                            const double d = have ? sv_d[i] : 0.0;
+                            const uint32_t p = have ? sv_pos[i] : 0u;
+                            const int32_t id = have ? sv_id[i] : 0;
+                            const bool keep = have && d <= cut;
+                            const unsigned long long bal = __ballot(keep);
+                            const uint32_t at = kept + __popcll(bal & ((1ull << lane) - 1ull));
+                            __syncthreads();  // every lane has read its entry before any slot is rewritten
+                            if (keep) {
+                                sv_d[at] = d;
+                                sv_pos[at] = p;
+                                sv_id[at] = id;
+                            }
+                            kept += __popcll(bal);
+                        }
+                        __syncthreads();
+                        ub = fmin(ub, cut);  // a bound of the true k-th distance, for later rings too
+                        if (kept == mm) break;  // ties only: nothing left to remove
+                        mm = kept;
+                    }
+                    return mm;
+                };
                 uint32_t m = 0;
-                for (int r = 0; r < nrows; r++) {
+                bool overflow = false;  // more equal-distance survivors than LDS holds
+                for (int r = 0; r < nrows && !overflow; r++) {
                     const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
                     // sparse index: lanes 0 and 1 search, the wave shares the two results
                     uint32_t jv = 0;
@@ -87,6 +127,14 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     const uint32_t jb = __builtin_amdgcn_readfirstlane(__shfl(jv, 0, 64)),
                                    je = __builtin_amdgcn_readfirstlane(__shfl(jv, 1, 64));
                     for (uint32_t j0 = jb; j0 < je; j0 += PC_WAVE) {
+                        if (m > SCAP - PC_WAVE) {  // wave-uniform: make room before the next 64 candidates
+                            __syncthreads();
+                            m = thin(m);
+                            if (m > SCAP - PC_WAVE) {
+                                overflow = true;
+                                break;
+                            }
+                        }
                         const uint32_t j = j0 + lane;
                         bool keep = false;
                         double d = 0.0;
@@ -102,7 +150,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                         }
                         const unsigned long long bal = __ballot(keep);
                         const uint32_t at = m + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (keep && at < SCAP) {
+                        if (keep) {
                             sv_d[at] = d;
                             sv_pos[at] = j;
                             sv_id[at] = pid;
@@ -111,44 +159,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     }
                 }
                 __syncthreads();
-                uint32_t mm = min(m, (uint32_t)SCAP);
-                // Thin the held survivors inside LDS before ranking them (ranking is quadratic): the
-                // k-th smallest of ANY 64 of them bounds the true k-th distance, so everything
-                // farther than it can go.  Repeat while that still removes something.
-                while (mm > 2 * PC_WAVE) {
-                    const double di = sv_d[lane];
-                    const int32_t ii = sv_id[lane];
-                    int rank = 0;
-                    for (int j = 0; j < PC_WAVE; j++) {
-                        const double dj = __shfl(di, j, 64);
-                        const int32_t ij = __shfl(ii, j, 64);
-                        rank += (dj < di || (dj == di && ij < ii)) ? 1 : 0;
-                    }
-                    const unsigned long long sel = __ballot(rank == k - 1);
-                    const double cut = __shfl(di, __ffsll((long long)sel) - 1, 64);  // k <= 64: one lane has it
-                    uint32_t kept = 0;
-                    for (uint32_t base = 0; base < mm; base += PC_WAVE) {
-                        const uint32_t i = base + lane;
-                        const bool have = i < mm;
-                        const double d = have ? sv_d[i] : 0.0;
-                        const uint32_t p = have ? sv_pos[i] : 0u;
-                        const int32_t id = have ? sv_id[i] : 0;
-                        const bool keep = have && d <= cut;
-                        const unsigned long long bal = __ballot(keep);
-                        const uint32_t at = kept + __popcll(bal & ((1ull << lane) - 1ull));
-                        __syncthreads();  // every lane has read its entry before any slot is rewritten
-                        if (keep) {
-                            sv_d[at] = d;
-                            sv_pos[at] = p;
-                            sv_id[at] = id;
-                        }
-                        kept += __popcll(bal);
-                    }
-                    __syncthreads();
-                    ub = fmin(ub, cut);  // a bound of the true k-th distance, for retries and later rings too
-                    if (kept == mm) break;  // ties only: nothing left to remove
-                    mm = kept;
+                if (overflow) {
+                    spilled = true;
+                    break;
                 }
+                const uint32_t mm = thin(m);
                 // rank the held survivors by (d2, original index)
                 for (uint32_t base = 0; base < mm; base += PC_WAVE) {
                     const uint32_t i = base + lane;
@@ -170,17 +185,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 cnt = (int)min(mm, (uint32_t)k);
                 const double kth = cnt == k ? res_d[k - 1] : INFINITY;
                 __syncthreads();
-                if (m > (uint32_t)SCAP) {
-                    // LDS held only part of the survivors: their k-th bounds the true k-th, so
-                    // retry the same block with it; without progress (ties) hand the query on
-                    if (cnt == k) ub = fmin(ub, kth);
-                    if (ub < ub_in && retries < 8) {
-                        retries++;
-                        continue;
-                    }
-                    spilled = true;
-                    break;
-                }
                 certified = can_end_short || (cnt == k && kth <= b2);
                 if (certified) {
                     // results refer to this level's records
@@ -203,7 +207,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             } else {
                 R++;
             }
-            retries = 0;
         }
         if (spilled && lane == 0) {
             const uint32_t p = atomicAdd(A.flag2_count, 1u);
