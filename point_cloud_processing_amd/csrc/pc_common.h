@@ -114,7 +114,6 @@ struct pc_grid {
     pc_grid *coarse = nullptr;
     int level = 0;        // 0: finest
     bool uneven = false;  // part of a multi-level index (set on every level)
-    bool refined = false; // cells halved beyond the average point's need (for the crowded parts)
 };
 
 // pc_grid.hip

@@ -268,17 +268,11 @@ __global__ __launch_bounds__(256) void k_row_runs(const uint32_t *__restrict__ k
 __global__ __launch_bounds__(256) void k_count_stats(const uint32_t *__restrict__ cnt, int64_t ncell,
                                                       unsigned long long *__restrict__ stats) {
     unsigned long long sq = 0, runs = 0;
-    __shared__ unsigned long long hist[32];  // points by the size class of their cell: [2^b, 2^(b+1))
-    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * 256) {
         const unsigned long long c = cnt[i];
         sq += c * c;
         runs += c ? 1 : 0;
-        if (c > 1) atomicAdd(&hist[63 - __clzll(c)], c);
     }
-    __syncthreads();
-    if (threadIdx.x >= 1 && threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], hist[threadIdx.x]);
     __shared__ unsigned long long red[2][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -301,9 +295,6 @@ __global__ __launch_bounds__(256) void k_count_stats(const uint32_t *__restrict_
 __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ keys, int64_t n,
                                                     unsigned long long *__restrict__ stats) {
     unsigned long long sq = 0, runs = 0;
-    __shared__ unsigned long long hist[32];
-    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-    __syncthreads();
     // grid-stride: a few thousand atomics in total instead of one pair per wave
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t key = keys[i];
@@ -327,11 +318,8 @@ __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ 
             }
             sq += (unsigned long long)(e - i) * (unsigned long long)(e - i);
             runs += 1;
-            if (e - i > 1) atomicAdd(&hist[63 - __clzll((unsigned long long)(e - i))], (unsigned long long)(e - i));
         }
     }
-    __syncthreads();
-    if (threadIdx.x >= 1 && threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&stats[2 + threadIdx.x], hist[threadIdx.x]);
     __shared__ unsigned long long red[2][4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -659,7 +647,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
             break;
         }
-        bool in_tmp = false, dense = true, refined = false;
+        bool in_tmp = false, dense = true;
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
         for (int attempt = 0; n > 0; attempt++) {
@@ -697,14 +685,14 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
                 hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
             }
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
-            if (hipMemsetAsync(stats.p, 0, 34 * 8, st) != hipSuccess) break;
+            if (hipMemsetAsync(stats.p, 0, 2 * 8, st) != hipSuccess) break;
             if (dense)
                 hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 512u)), dim3(256), 0, st,
                                    g->cell_start, g->ncell, stats.as<unsigned long long>());
             else
                 hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st, sorted_keys,
                                    n, stats.as<unsigned long long>());
-            if (hipMemcpyAsync(hs, stats.p, 34 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            if (hipMemcpyAsync(hs, stats.p, 2 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) {
                 rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
                 break;
@@ -715,33 +703,8 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             if (getenv("PC_AMD_DEBUG") && automatic)
                 fprintf(stderr, "[pc_amd]   grid attempt %d: cell %.4g cells %lld occupied %lld seen %.1f (target %.1f)\n", attempt,
                         cell, (long long)g->ncell, (long long)g->occupied, seen, target);
-            if (!automatic || attempt >= 8 || refined) break;
-            if (seen <= 2.0 * (target + 1.0)) {
-                // The average point is served.  Points in cells several times fuller (dense patches,
-                // cluster cores) would overflow the candidate block of the tile kernel at EVERY level
-                // (coarser cells are fuller still): if more than one point in fifty sits in such cells,
-                // make the finest level fine enough for them; the coarser levels serve the rest.
-                const double crowded = 64.0;  // ~ block capacity / cells a surface crosses in a block
-                double top = 1.0;             // upper edge of the size class holding the 98 % point
-                unsigned long long acc = 0;
-                for (int b = 31; b >= 1; b--) {  // from the fullest size class down
-                    acc += hs[2 + b];
-                    if ((double)acc > 0.02 * (double)n) {
-                        top = ldexp(2.0, b);
-                        break;
-                    }
-                }
-                if (top <= crowded || (double)hs[1] >= 0.85 * (1.0 - exp(-(double)n / (double)g->ncell)) * (double)g->ncell) break;
-                const int f = std::min(3, std::max(1, (int)ceil(0.5 * log2(top / 32.0))));
-                int32_t dim2[3];
-                const double got = fit_dims(cell / (double)(1 << f), dim2);
-                if (got > 0.93 * cell) break;
-                cell = got;
-                for (int a = 0; a < 3; a++) g->gp.dim[a] = dim2[a];
-                refined = true;
-                g->refined = true;
-                continue;
-            }
+            if (!automatic || attempt >= 8) break;
+            if (seen <= 2.0 * (target + 1.0)) break;
             int32_t dim2[3];
             const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
             const double got = fit_dims(want, dim2);

@@ -717,7 +717,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         // says nothing about a cloud whose points sit mostly in a few full tiles among many empty ones
         const double pop = (double)g->n / (double)std::max<int64_t>(1, g->tile_count);
         const double cell_mean = (double)g->n / (double)std::max<int64_t>(1, g->occupied);
-        if (pop >= 16.0 || g->occupied <= 0 || g->refined || g->seen > 2.0 * (cell_mean + 1.0)) break;
+        if (pop >= 16.0 || g->occupied <= 0 || g->seen > 2.0 * (cell_mean + 1.0)) break;
         int t2[3];
         bool changed = false;
         for (int a = 0; a < 3; a++) {
