@@ -537,6 +537,26 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
             }
         }
         cnt = min(cnt, k);
+        if (MODE == M_KNN) {
+            // rows straight from the sorted registers (no second look at the candidates)
+            const int64_t row = (int64_t)qid * k;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                if (s < k) {  // wave-uniform
+                    const bool have = s < cnt;
+                    if (A.out_idx) A.out_idx[row + s] = have ? orig_index(od[s]) : -1;
+                    if (A.out_d2) {
+                        const double d = have ? dd[s] : INFINITY;
+                        if (A.d2_f64)
+                            reinterpret_cast<double *>(A.out_d2)[row + s] = d;
+                        else
+                            reinterpret_cast<float *>(A.out_d2)[row + s] = (float)d;
+                    }
+                }
+            }
+            if (A.out_cnt) A.out_cnt[qid] = cnt;
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < KS; s++)
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];

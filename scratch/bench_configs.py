@@ -130,3 +130,29 @@ def filter_case(name, pts):
 if "icp" in which: icp_case("C5 torus 2M vs 2M", 2_000_000)
 if "radius" in which: radius_case("radius count sphere 1M", D.bumpy_sphere(1_000_000, 5)); radius_case("radius count uniform 1M", D.uniform_cube(1_000_000, 2))
 if "filter" in which: filter_case("filter_pcd sphere 1M", D.bumpy_sphere(1_000_000, 5))
+
+def c3_frames(nframes=60):
+    """BASELINE config 3: a stream of LiDAR frames, voxel 0.1 m -> grid -> kNN(30) + normals; per-frame latency"""
+    frames = [torch.from_numpy(D.lidar_frame(4 + f).astype(np.float32)).to(eng.device) for f in range(8)]
+    n = len(frames[0]); k = 30
+    out = torch.empty((n, 3), dtype=torch.float64, device=eng.device)
+    nrm = torch.empty((n, 3), dtype=torch.float64, device=eng.device)
+    m = C.c_int64(0)
+    lat = []
+    for f in range(nframes + 5):
+        xyz = frames[f % len(frames)]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng._check(lib.pc_voxel_downsample(ctx, _ptr(xyz), _lib.PC_F32, None, None, n, 0.1, _ptr(out), None, None,
+                                           None, None, C.byref(m), eng.stream()), "voxel")
+        mm = m.value
+        h = C.c_void_p()
+        eng._check(lib.pc_grid_build(ctx, _ptr(out), _lib.PC_F64, mm, 0.0, k, C.byref(h), eng.stream()), "grid")
+        eng._check(lib.pc_normals(ctx, h, 0, mm, k, -1.0, None, _ptr(nrm), eng.stream()), "normals")
+        torch.cuda.synchronize()
+        lib.pc_grid_destroy(ctx, h)
+        if f >= 5: lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.sort(np.array(lat))
+    print(f"C3 stream: {nframes} frames of {n} points -> ~{mm} voxels: p50 {np.percentile(lat,50):.2f} ms  p99 {np.percentile(lat,99):.2f} ms  "
+          f"({n/np.percentile(lat,50)*1e3/1e6:.1f} M input points/s)", flush=True)
+
+if "c3frames" in which: c3_frames()
