@@ -54,6 +54,7 @@ __device__ inline uint32_t lds_read_u32(uint32_t addr) {
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+__device__ inline void lds_write_u32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v)); }
 __device__ inline void lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
 
 template <int KS>
@@ -315,9 +316,10 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
         // few keys too many through: the final list is the same KS smallest keys either way.
         uint32_t thr = KEY_EMPTY;
         lds_u32 *const col = (lds_u32 *)selbuf + lane;  // slot s of this lane: col[s * 64]
-        lds_u32 *wp = col;                                                 // next free slot
+        const uint32_t col_a = (uint32_t)(uintptr_t)col;                   // LDS byte address of the column
+        uint32_t wp = col_a - 4u * PC_WAVE;                                // last written slot (byte address)
         auto drain = [&]() {
-            const uint32_t have = (uint32_t)(wp - col) >> 6;
+            const uint32_t have = (wp + 4u * PC_WAVE - col_a) >> 8;
             uint32_t ra = (uint32_t)(uintptr_t)col;
             uint32_t nxt = lds_read_u32(ra);
             uint32_t s = 0;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
             } while (__any(s < have));
             lds_wait(nxt);
             thr = L[KS - 1];
-            wp = col;
+            wp = col_a - 4u * PC_WAVE;
         };
         int qc[3];
         {
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         const uint32_t cand_a = (uint32_t)(uintptr_t)(const lds_f32 *)cxyz;  // LDS byte address
         const uint32_t pa_last = cand_a + 12u * (ncand - 1);
-        lds_u32 *const wp_full = col + (SEL_SLOTS - 1) * PC_WAVE;
+        const uint32_t wp_full = col_a + 4u * (SEL_SLOTS - 2) * PC_WAVE;  // (wp names the last written slot)
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
             const uint32_t start = seg_pack[seg] & 0xffffu;
@@ -397,12 +399,12 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
                 const uint32_t k0 = (__float_as_uint(d.x) & ~ORD_MASK) | j0;
                 const uint32_t k1 = (__float_as_uint(d.y) & ~ORD_MASK) | j1;
                 if (j0 < end && k0 < thr) {
-                    *wp = k0;
-                    wp += PC_WAVE;
+                    wp += 4u * PC_WAVE;
+                    lds_write_u32(wp, k0);
                 }
                 if (j1 < end && k1 < thr) {
-                    *wp = k1;
-                    wp += PC_WAVE;
+                    wp += 4u * PC_WAVE;
+                    lds_write_u32(wp, k1);
                 }
                 j0 += 2;
                 j1 += 2;
