@@ -101,9 +101,13 @@ struct TileRec<Rec64> {
     }
 };
 
+// One tile (first cell c0, extent ext cells) answered by the whole workgroup.  Returns 1, having done
+// nothing, if the tile's block holds more candidates than LDS and may_split allows the caller to come
+// back with smaller tiles; 0 otherwise.  Every return is uniform over the workgroup.
 template <typename REC, int KS, int MODE>
-__global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const int (&c0)[3], const int (&ext)[3],
+                                         const bool may_split) {
+    __syncthreads();  // a previous call of this workgroup is done with LDS
     // candidate block: xyz packed at a 12-byte stride (+ two pad slots) and the 4th word apart.  The
     // pair (j, j+1) of one coordinate is then ONE ds_read2_b32 at immediate offsets (0,3), (1,4),
     // (2,5) from a single address and lands as a register pair for packed fp32 math.
@@ -125,25 +129,10 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
     const CellIndex &qix = A.qrec ? A.qci : A.ci;
     const int k = A.k;
 
-    // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
-    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Remap so
-    // that each XCD walks one contiguous eighth of the tile sequence: x/y-neighbouring tiles, whose
-    // halos overlap, then hit the same L2 (placement is a speed matter only, never correctness).
-    uint32_t bid = blockIdx.x;
-    {
-        const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = bid & 7u;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid;
-    const int tx = (int)(t % A.ntile[0]);
-    t /= A.ntile[0];
-    const int ty = (int)(t % A.ntile[1]);
-    const int tz = (int)(t / A.ntile[1]);
-    const int c0[3] = {tx * A.tile[0], ty * A.tile[1], tz * A.tile[2]};  // first cell of the tile
     int c1[3], lo[3], hi[3];                                              // last cell; block bounds
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        c1[a] = min(c0[a] + A.tile[a], gp.dim[a]) - 1;
+        c1[a] = min(c0[a] + ext[a], gp.dim[a]) - 1;
         lo[a] = max(c0[a] - 1, 0);
         hi[a] = min(c1[a] + 1, gp.dim[a] - 1);
     }
@@ -183,10 +172,12 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
     }
     const uint32_t ncand = __builtin_amdgcn_readfirstlane(__shfl(cand_off, 63, 64));
     const uint32_t nquery = __builtin_amdgcn_readfirstlane(__shfl(q_off, 63, 64));
-    if (nquery == 0) return;  // wave-uniform
+    if (nquery == 0) return 0;  // uniform
     cand_off -= row_cnt;      // exclusive
     q_off -= q_cnt;
-    if (A.qflag_in && (ncand > (uint32_t)A.cand_cap)) return;  // flagged points of an over-full block stay flagged
+    const bool too_many = ncand > (uint32_t)A.cand_cap;
+    const bool splittable = may_split && (ext[0] > 1 || ext[1] > 1 || ext[2] > 1);
+    if (A.qflag_in && too_many && !splittable) return 0;  // flagged points of an over-full block stay flagged
     if (A.qflag_in) {
         // later passes answer only the points an earlier pass flagged: leave if the tile has none
         bool any = false;
@@ -208,8 +199,9 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
                 any = any || A.qflag_in[id] != 0;
             }
         }
-        if (!__any(any)) return;
+        if (!__any(any)) return 0;
     }
+    if (too_many && splittable) return 1;
 
     // over-full blocks do not fit LDS; blocks with fewer than k points cannot certify anything unless
     // they are the whole grid: both go straight to the re-run list
@@ -572,6 +564,54 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
                               d += dz * dz;
                           });
     }
+    return 0;
+}
+
+template <typename REC, int KS, int MODE, bool SPLIT>
+__global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Remap so
+    // that each XCD walks one contiguous eighth of the tile sequence: x/y-neighbouring tiles, whose
+    // halos overlap, then hit the same L2 (placement is a speed matter only, never correctness).
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = bid & 7u;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid;
+    const int tx = (int)(t % A.ntile[0]);
+    t /= A.ntile[0];
+    const int ty = (int)(t % A.ntile[1]);
+    const int tz = (int)(t / A.ntile[1]);
+    const int c0[3] = {tx * A.tile[0], ty * A.tile[1], tz * A.tile[2]};  // first cell of the tile
+    const int ext[3] = {A.tile[0], A.tile[1], A.tile[2]};
+    if (!SPLIT) {  // (clouds that fill their box: the tile shape was sized for the LDS capacity)
+        tile_body<REC, KS, MODE>(A, smem, c0, ext, false);
+        return;
+    }
+    // The whole tile first; if its block is too full for LDS, its (up to) eight half-size parts
+    // one after the other: big tiles fill the waves where the cloud is thin without giving up
+    // the dense parts.
+    const int half[3] = {(ext[0] + 1) / 2, (ext[1] + 1) / 2, (ext[2] + 1) / 2};
+    int nsub = 0;
+    for (int sub = -1; sub < nsub; sub++) {
+        int sc0[3], sext[3];
+        bool empty = false;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int hi_part = sub < 0 ? 0 : (sub >> a) & 1;
+            sc0[a] = c0[a] + hi_part * half[a];
+            sext[a] = sub < 0 ? ext[a] : (hi_part ? ext[a] - half[a] : half[a]);
+            empty |= sext[a] <= 0 || sc0[a] >= A.gp.dim[a];
+        }
+        if (empty) continue;
+        const int again = tile_body<REC, KS, MODE>(A, smem, sc0, sext, sub < 0);
+        if (sub < 0) {
+            if (!again) break;
+            nsub = 8;
+        }
+    }
 }
 
 // ---- occupied tiles of a sparse grid -------------------------------------------------------------
@@ -722,7 +762,9 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         // sparser ones wait for a coarser one).  Start from a 2x2x2 tile (a single cell on the coarser
         // levels, whose open points sit in fuller cells) and grow it while the occupied tiles hold
         // too few points to fill a wave (thin surfaces, scan lines); the shape is settled below.
-        for (int a = 0; a < 3; a++) best[a] = g->level > 0 ? 1 : std::min(2, std::max(1, (int)g->gp.dim[a]));
+        int base = g->level > 0 ? 1 : 2;
+        if (const char *e = getenv(g->level > 0 ? "PC_AMD_UNEVEN_TILE1" : "PC_AMD_UNEVEN_TILE0")) base = std::max(1, atoi(e));
+        for (int a = 0; a < 3; a++) best[a] = std::min(std::min(base, a == 0 ? MAX_NX - 2 : 6), std::max(1, (int)g->gp.dim[a]));
         expect = UNEVEN_CAP;
     }
     int cap = ((int)expect + 63) / 64 * 64;
@@ -777,30 +819,27 @@ __global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__
     }
 }
 
-template <typename REC, int KS>
+template <typename REC, int KS, bool SPLIT>
 void launch_tile(int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
+    const dim3 grid(nblocks), block(PC_WAVE * nw);
     switch (mode) {
-        case M_KNN: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_KNN>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A); break;
-        case M_SOR: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_SOR>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A); break;
-        case M_NORMALS:
-            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NORMALS>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A);
-            break;
-        case M_NNDIST:
-            hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NNDIST>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A);
-            break;
-        case M_ALL: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_ALL>), dim3(nblocks), dim3(PC_WAVE * nw), lds, st, A); break;
+        case M_KNN: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_KNN, SPLIT>), grid, block, lds, st, A); break;
+        case M_SOR: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_SOR, SPLIT>), grid, block, lds, st, A); break;
+        case M_NORMALS: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NORMALS, SPLIT>), grid, block, lds, st, A); break;
+        case M_NNDIST: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NNDIST, SPLIT>), grid, block, lds, st, A); break;
+        case M_ALL: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_ALL, SPLIT>), grid, block, lds, st, A); break;
         default: break;
     }
 }
 
-template <typename REC>
+template <typename REC, bool SPLIT>
 void launch_tile_ks(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
     switch (ks) {
-        case 4: launch_tile<REC, 4>(mode, nblocks, nw, lds, st, A); break;
-        case 10: launch_tile<REC, 10>(mode, nblocks, nw, lds, st, A); break;
-        case 18: launch_tile<REC, 18>(mode, nblocks, nw, lds, st, A); break;
-        case 22: launch_tile<REC, 22>(mode, nblocks, nw, lds, st, A); break;
-        default: launch_tile<REC, 34>(mode, nblocks, nw, lds, st, A); break;
+        case 4: launch_tile<REC, 4, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 10: launch_tile<REC, 10, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 18: launch_tile<REC, 18, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 22: launch_tile<REC, 22, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        default: launch_tile<REC, 34, SPLIT>(mode, nblocks, nw, lds, st, A); break;
     }
 }
 
@@ -886,10 +925,17 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
                            sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
                            nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
-        if (g->dtype == PC_F32)
-            launch_tile_ks<Rec32>(ks, mode, (unsigned)nt, nw, lds, st, A);
-        else
-            launch_tile_ks<Rec64>(ks, mode, (unsigned)nt, nw, lds, st, A);
+        if (g->dtype == PC_F32) {
+            if (l->uneven)
+                launch_tile_ks<Rec32, true>(ks, mode, (unsigned)nt, nw, lds, st, A);
+            else
+                launch_tile_ks<Rec32, false>(ks, mode, (unsigned)nt, nw, lds, st, A);
+        } else {
+            if (l->uneven)
+                launch_tile_ks<Rec64, true>(ks, mode, (unsigned)nt, nw, lds, st, A);
+            else
+                launch_tile_ks<Rec64, false>(ks, mode, (unsigned)nt, nw, lds, st, A);
+        }
         PC_HIP(hipGetLastError());
         if (qflag) {
             // how many points are still open decides whether another (coarser) pass is worth it
