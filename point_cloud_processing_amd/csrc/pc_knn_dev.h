@@ -363,5 +363,11 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
 // pc_knn_tile.hip: the tile-cooperative fast path (self-queries, k <= 32).
 // Returns PC_OK after enqueueing; *handled = false when the configuration is not supported.
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled);
+// pc_knn_tile_*.hip: the tile kernel for one record type, with / without sub-tile splitting
+void pc_tile_launch_f32(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
+void pc_tile_launch_f32_split(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
+void pc_tile_launch_f64(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
+void pc_tile_launch_f64_split(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
+
 // pc_knn_wave.hip: one wave per listed query (A.qlist / A.qub / A.qcount).
 int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A, hipStream_t st);

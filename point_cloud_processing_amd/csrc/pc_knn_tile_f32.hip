@@ -1,0 +1,6 @@
+// Tile kernel instantiations: Rec32 records, without sub-tile splitting.
+#include "pc_knn_tile_kernel.h"
+
+void pc_tile_launch_f32(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
+    launch_tile_ks<Rec32, false>(ks, mode, nblocks, nw, lds, st, A);
+}

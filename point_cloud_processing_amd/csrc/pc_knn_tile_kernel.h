@@ -1,0 +1,624 @@
+// Device side of the tile-cooperative exact kNN (see pc_knn_tile.hip for the overview): constants,
+// the kernel and its launch switch.  Included by the host file and by one small translation unit per
+// (record type, split) pair so that the instantiations compile in parallel.
+#pragma once
+#include "pc_knn_dev.h"
+
+namespace {
+
+constexpr int ORD_BITS = 11;
+constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may stage (32 KiB of LDS)
+constexpr uint32_t ORD_MASK = CAND_CAP_MAX - 1;
+constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_f32;    // 32-bit LDS addresses: no 64-bit pointer math
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr int MAX_ROWS = 64;  // (tile_y + 2) * (tile_z + 2) must fit one wave
+constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most
+constexpr int MAX_TILE_WAVES = 4;  // waves of one workgroup, all working on the same staged block
+constexpr int UNEVEN_CAP = 1024;   // candidate capacity of the tiles of multi-level indexes
+constexpr int SEL_SLOTS = 16; // parked keys per lane between two sorted insertions
+
+// LDS reads whose pairing and issue point the compiler must not rearrange.  The values are valid only
+// after lds_wait(), which is tied to them through its operands.
+__device__ inline void lds_read_xyz_pair(uint32_t addr, f32x2 &x, f32x2 &y, f32x2 &z) {
+    asm volatile(
+        "ds_read2_b32 %0, %3 offset1:3\n\t"
+        "ds_read2_b32 %1, %3 offset0:1 offset1:4\n\t"
+        "ds_read2_b32 %2, %3 offset0:2 offset1:5"
+        : "=&v"(x), "=&v"(y), "=&v"(z)
+        : "v"(addr));
+}
+__device__ inline void lds_wait(f32x2 &x, f32x2 &y, f32x2 &z) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y), "+v"(z));
+}
+__device__ inline uint32_t lds_read_u32(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ inline void lds_write_u32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v)); }
+__device__ inline void lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+
+template <int KS>
+__device__ inline void list_insert(uint32_t (&L)[KS], uint32_t key) {
+#pragma unroll
+    for (int s = KS - 1; s > 0; s--) asm("v_med3_u32 %0, %1, %2, %0" : "+v"(L[s]) : "v"(L[s - 1]), "v"(key));
+    asm("v_min_u32 %0, %0, %1" : "+v"(L[0]) : "v"(key));
+}
+
+// How the two record types appear in the LDS candidate block.
+//  fp32 grids: the record itself {x, y, z, original index}: fp32 differences of the stored values
+//              carry only a relative rounding error.
+//  fp64 grids: {x, y, z relative to the block origin, rounded to fp32; sorted position}: the filter
+//              works on rounded coordinates, so its keys carry an ABSOLUTE error of at most
+//              ~2^-21 * block extent on the distance, which the certification bound subtracts; the
+//              exact finish re-reads the fp64 record by its sorted position.
+template <typename REC>
+struct TileRec;
+template <>
+struct TileRec<Rec32> {
+    static constexpr bool kRelative = false;
+    __device__ static inline float4 stage(const Rec32 *rec, uint32_t src, const double *) {
+        return *reinterpret_cast<const float4 *>(rec + src);
+    }
+    __device__ static inline void exact(const Rec32 *, const float4 &c, double &x, double &y, double &z, int32_t &id) {
+        x = (double)c.x;
+        y = (double)c.y;
+        z = (double)c.z;
+        id = __float_as_int(c.w);
+    }
+};
+template <>
+struct TileRec<Rec64> {
+    static constexpr bool kRelative = true;
+    __device__ static inline float4 stage(const Rec64 *rec, uint32_t src, const double *org) {
+        double x, y, z;
+        int32_t id;
+        RecTraits<Rec64>::load(rec + src, x, y, z, id);
+        return make_float4((float)(x - org[0]), (float)(y - org[1]), (float)(z - org[2]), __uint_as_float(src));
+    }
+    __device__ static inline void exact(const Rec64 *rec, const float4 &c, double &x, double &y, double &z,
+                                        int32_t &id) {
+        RecTraits<Rec64>::load(rec + __float_as_uint(c.w), x, y, z, id);
+    }
+};
+
+// One tile (first cell c0, extent ext cells) answered by the whole workgroup.  Returns 1, having done
+// nothing, if the tile's block holds more candidates than LDS and may_split allows the caller to come
+// back with smaller tiles; 0 otherwise.  Every return is uniform over the workgroup.
+template <typename REC, int KS, int MODE>
+__device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const int (&c0)[3], const int (&ext)[3],
+                                         const bool may_split) {
+    __syncthreads();  // a previous call of this workgroup is done with LDS
+    // candidate block: xyz packed at a 12-byte stride (+ two pad slots) and the 4th word apart.  The
+    // pair (j, j+1) of one coordinate is then ONE ds_read2_b32 at immediate offsets (0,3), (1,4),
+    // (2,5) from a single address and lands as a register pair for packed fp32 math.
+    const int cstride = A.cand_cap + 2;
+    float *cxyz = reinterpret_cast<float *>(smem), *cws = cxyz + 3 * cstride;
+    uint32_t *row_src = reinterpret_cast<uint32_t *>(cws + cstride);                               // [64] begin
+    uint32_t *row_off = row_src + MAX_ROWS;                                                        // [65] offsets
+    uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_off + MAX_ROWS + 4);                     // [64][MAX_NX+1]
+    // one area of lane-private columns: parked keys during the filter, result order afterwards
+    const int tid = threadIdx.x, lane = tid & (PC_WAVE - 1), wid = tid >> 6, nthr = blockDim.x;
+    // (one such area per wave)
+    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_off + MAX_ROWS * (MAX_NX + 1)) +
+                       wid * max(PC_WAVE * (SEL_SLOTS + 1), (PC_WAVE / 2) * A.k);           // [SEL_SLOTS + 1][64]
+    uint16_t *ordbuf = reinterpret_cast<uint16_t *>(selbuf);                                       // [k][64]
+    const GridParams &gp = A.gp;
+    const REC *rec = reinterpret_cast<const REC *>(A.rec);
+    // where the queries come from: the grid's own records, or external queries binned into the grid
+    const REC *qsrc = A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec;
+    const CellIndex &qix = A.qrec ? A.qci : A.ci;
+    const int k = A.k;
+
+    int c1[3], lo[3], hi[3];                                              // last cell; block bounds
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        c1[a] = min(c0[a] + ext[a], gp.dim[a]) - 1;
+        lo[a] = max(c0[a] - 1, 0);
+        hi[a] = min(c1[a] + 1, gp.dim[a] - 1);
+    }
+    const int nry = hi[1] - lo[1] + 1, nrz = hi[2] - lo[2] + 1;
+    const int nrows = nry * nrz;  // <= MAX_ROWS by construction of the tile shape
+    // block origin and extent (world units): the frame of the fp32 filter of fp64 grids
+    const double org[3] = {gp.o[0] + (double)lo[0] * gp.cell, gp.o[1] + (double)lo[1] * gp.cell,
+                           gp.o[2] + (double)lo[2] * gp.cell};
+    const double bext = gp.cell * (double)max(max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) + gp.cell;
+
+    // ---- row table: lane r describes block row r -------------------------------------------------
+    uint32_t row_begin = 0, row_cnt = 0, q_begin = 0, q_cnt = 0;
+    if (lane < nrows) {
+        const int y = lo[1] + lane % nry, z = lo[2] + lane / nry;
+        const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+        row_begin = cell_begin(A.ci, row + lo[0]);
+        row_cnt = cell_begin(A.ci, row + hi[0] + 1) - row_begin;
+        if (y >= c0[1] && y <= c1[1] && z >= c0[2] && z <= c1[2]) {  // a row of the tile itself
+            q_begin = cell_begin(qix, row + c0[0]);
+            q_cnt = cell_begin(qix, row + c1[0] + 1) - q_begin;
+            if (!A.qflag_in && !A.qrec) {  // first pass: restrict to the caller's sorted-position range
+                const int64_t b = max((int64_t)q_begin, A.s_begin), e = min((int64_t)q_begin + q_cnt, A.s_end);
+                q_begin = (uint32_t)b;
+                q_cnt = e > b ? (uint32_t)(e - b) : 0u;
+            }
+        }
+    }
+    // inclusive prefix sums over the rows (wave scan)
+    uint32_t cand_off = row_cnt, q_off = q_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(cand_off, o, 64), b = __shfl_up(q_off, o, 64);
+        if (lane >= o) {
+            cand_off += a;
+            q_off += b;
+        }
+    }
+    const uint32_t ncand = __builtin_amdgcn_readfirstlane(__shfl(cand_off, 63, 64));
+    const uint32_t nquery = __builtin_amdgcn_readfirstlane(__shfl(q_off, 63, 64));
+    if (nquery == 0) return 0;  // uniform
+    cand_off -= row_cnt;      // exclusive
+    q_off -= q_cnt;
+    const bool too_many = ncand > (uint32_t)A.cand_cap;
+    const bool splittable = may_split && (ext[0] > 1 || ext[1] > 1 || ext[2] > 1);
+    if (A.qflag_in && too_many && !splittable) return 0;  // flagged points of an over-full block stay flagged
+    if (A.qflag_in) {
+        // later passes answer only the points an earlier pass flagged: leave if the tile has none
+        bool any = false;
+        for (uint32_t qbase = 0; qbase < nquery; qbase += PC_WAVE) {
+            const uint32_t qo = qbase + lane;
+            uint32_t sp = 0;
+            bool have = false;
+            for (int r = 0; r < nrows; r++) {
+                const uint32_t ob = __shfl(q_off, r, 64), oc = __shfl(q_cnt, r, 64), gb = __shfl(q_begin, r, 64);
+                if (qo < nquery && qo >= ob && qo < ob + oc) {
+                    sp = gb + (qo - ob);
+                    have = true;
+                }
+            }
+            if (have) {
+                double x, y, z;
+                int32_t id;
+                RecTraits<REC>::load(qsrc + sp, x, y, z, id);
+                any = any || A.qflag_in[id] != 0;
+            }
+        }
+        if (!__any(any)) return 0;
+    }
+    if (too_many && splittable) return 1;
+
+    // over-full blocks do not fit LDS; blocks with fewer than k points cannot certify anything unless
+    // they are the whole grid: both go straight to the re-run list
+    const bool whole_grid = lo[0] == 0 && lo[1] == 0 && lo[2] == 0 && hi[0] == gp.dim[0] - 1 &&
+                            hi[1] == gp.dim[1] - 1 && hi[2] == gp.dim[2] - 1;
+    const bool overfull = ncand > (uint32_t)A.cand_cap || (ncand < (uint32_t)k && !whole_grid && A.radius2 < 0.0);
+
+    // ---- stage the candidate block into LDS ------------------------------------------------------
+    // flattened over the block's candidates: lane i copies candidates i, i+64, ...; the row of a
+    // candidate follows from the row offsets, and four 16-byte loads are in flight per lane
+    row_src[lane] = row_begin;
+    row_off[lane] = cand_off;
+    if (lane == 0) row_off[MAX_ROWS] = ncand;
+    __syncthreads();
+    if (!overfull) {
+        int r = 0;
+        for (uint32_t base = 0; base < ncand; base += 4 * nthr) {
+            uint32_t src[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t i = base + b * nthr + tid;
+                src[b] = 0;
+                if (i < ncand) {
+                    while (r + 1 < nrows && i >= row_off[r + 1]) r++;
+                    src[b] = row_src[r] + (i - row_off[r]);
+                }
+            }
+            float4 v[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) v[b] = TileRec<REC>::stage(rec, src[b], org);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t i = base + b * nthr + tid;
+                if (i < ncand) {
+                    cxyz[3 * i] = v[b].x;
+                    cxyz[3 * i + 1] = v[b].y;
+                    cxyz[3 * i + 2] = v[b].z;
+                    cws[i] = v[b].w;
+                }
+            }
+        }
+    }
+    // block-relative offset of every cell boundary of every block row
+    const int nx = hi[0] - lo[0] + 1;
+    for (int e = tid; e < nrows * (nx + 1); e += nthr) {
+        const int r = e / (nx + 1), i = e - r * (nx + 1);
+        const int y = lo[1] + r % nry, z = lo[2] + r / nry;
+        const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+        cell_off[r * (MAX_NX + 1) + i] = (uint16_t)(row_off[r] + (cell_begin(A.ci, row + lo[0] + i) - row_src[r]));
+    }
+    __syncthreads();
+
+    const double eps = 1e-7 * gp.cell;
+    const double r2lim = A.radius2;
+
+    for (uint32_t qbase = wid * PC_WAVE; qbase < nquery; qbase += nthr) {  // the waves share the tile's queries
+        const uint32_t qo = qbase + lane;
+        const bool active = qo < nquery;
+        // which tile row holds query ordinal qo
+        uint32_t spos = 0;
+        for (int r = 0; r < nrows; r++) {  // shuffles stay outside divergent control flow
+            const uint32_t ob = __shfl(q_off, r, 64), oc = __shfl(q_cnt, r, 64), gb = __shfl(q_begin, r, 64);
+            if (active && qo >= ob && qo < ob + oc) spos = gb + (qo - ob);
+        }
+        double qxd = 0.0, qyd = 0.0, qzd = 0.0;
+        int32_t qid = 0;
+        bool live = active;  // a query this pass has to answer
+        if (active) {
+            RecTraits<REC>::load(qsrc + spos, qxd, qyd, qzd, qid);
+            if (A.qflag_in) live = A.qflag_in[qid] != 0;
+        }
+        if (!__any(live)) continue;
+        if (overfull) {
+            if (live) {
+                if (A.qflag_out) {
+                    A.qflag_out[qid] = 1;
+                    if (!A.qflag_in) A.qub_arr[qid] = INFINITY;
+                } else {
+                    const uint32_t p = atomicAdd(A.flag_count, 1u);
+                    if (p < A.flag_cap) {
+                        A.flag_list[p] = (int32_t)spos;
+                        A.flag_ub[p] = A.qflag_in ? A.qub_arr[qid] : INFINITY;
+                    }
+                }
+            }
+            continue;
+        }
+        // filter coordinates: the stored fp32 values, or fp32 offsets from the block origin
+        const float qx = TileRec<REC>::kRelative ? (float)(qxd - org[0]) : (float)qxd;
+        const float qy = TileRec<REC>::kRelative ? (float)(qyd - org[1]) : (float)qyd;
+        const float qz = TileRec<REC>::kRelative ? (float)(qzd - org[2]) : (float)qzd;
+
+        uint32_t L[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) L[s] = KEY_EMPTY;
+
+        // ---- stage 1: fp32 filter over the lane's own 3x3x3 cells --------------------------------
+        // Lanes of one cell walk the same LDS range (broadcast reads); the nine (dy, dz) row
+        // segments are visited in lock-step, each for the longest segment any lane has.
+        // A key can enter the list only if it is below the list's current last entry.  The lane
+        // keeps a copy `thr` of that entry and parks the keys below it in its own column of selbuf;
+        // the (expensive) sorted insertion runs over the parked keys only, when some lane's column
+        // is nearly full and once more at the end.  `thr` lags behind the list, which only lets a
+        // few keys too many through: the final list is the same KS smallest keys either way.
+        uint32_t thr = KEY_EMPTY;
+        lds_u32 *const col = (lds_u32 *)selbuf + lane;  // slot s of this lane: col[s * 64]
+        const uint32_t col_a = (uint32_t)(uintptr_t)col;                   // LDS byte address of the column
+        uint32_t wp = col_a - 4u * PC_WAVE;                                // last written slot (byte address)
+        auto drain = [&]() {
+            const uint32_t have = (wp + 4u * PC_WAVE - col_a) >> 8;
+            uint32_t ra = (uint32_t)(uintptr_t)col;
+            uint32_t nxt = lds_read_u32(ra);
+            uint32_t s = 0;
+            do {  // at least one round: a round of empty keys changes nothing
+                lds_wait(nxt);
+                const uint32_t key = s < have ? nxt : KEY_EMPTY;
+                ra += 4 * PC_WAVE;
+                nxt = lds_read_u32(ra);  // one slot ahead (the area has a spare row)
+                list_insert<KS>(L, key);
+                s++;
+            } while (__any(s < have));
+            lds_wait(nxt);
+            thr = L[KS - 1];
+            wp = col_a - 4u * PC_WAVE;
+        };
+        int qc[3];
+        {
+            const double qf[3] = {qxd, qyd, qzd};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double tt = floor((qf[a] - gp.o[a]) * gp.s);
+                qc[a] = !(tt > 0.0) ? 0 : (tt >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)tt);
+            }
+        }
+        const int i0 = max(qc[0] - 1, 0) - lo[0], i1 = min(qc[0] + 1, gp.dim[0] - 1) - lo[0] + 1;
+        // the nine (start, length) pairs and the wave-wide longest length of each, up front:
+        // the nine max-reductions overlap instead of serialising in front of every segment.
+        // Order: the query's own row, the four rows sharing a face with it, the four diagonal ones,
+        // so that the threshold tightens early.
+        constexpr int SEG_DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+        constexpr int SEG_DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        uint32_t seg_pack[9];  // start | len << 16
+        int seg_max[9];
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) {
+            const int y = qc[1] + SEG_DY[seg], z = qc[2] + SEG_DZ[seg];
+            uint32_t st = 0, ln = 0;
+            if (live && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2]) {
+                const int r = (y - lo[1]) + nry * (z - lo[2]);
+                st = cell_off[r * (MAX_NX + 1) + i0];
+                ln = cell_off[r * (MAX_NX + 1) + i1] - st;
+            }
+            seg_pack[seg] = st | (ln << 16);
+            seg_max[seg] = (int)ln;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int seg = 0; seg < 9; seg++) seg_max[seg] = max(seg_max[seg], __shfl_xor(seg_max[seg], o, 64));
+        }
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) seg_max[seg] = __builtin_amdgcn_readfirstlane(seg_max[seg]);
+        const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        const uint32_t cand_a = (uint32_t)(uintptr_t)(const lds_f32 *)cxyz;  // LDS byte address
+        const uint32_t pa_last = cand_a + 12u * (ncand - 1);
+        const uint32_t wp_full = col_a + 4u * (SEL_SLOTS - 2) * PC_WAVE;  // (wp names the last written slot)
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) {
+            const uint32_t start = seg_pack[seg] & 0xffffu;
+            const uint32_t end = start + (seg_pack[seg] >> 16);
+            const int tmax = seg_max[seg];
+            // two candidates per step: one ds_read2_b32 per coordinate, packed fp32 math
+            // (v_pk_add/mul/fma_f32); the next pair is requested as soon as this one is consumed
+            uint32_t pa = min(cand_a + 12u * start, pa_last);
+            f32x2 nx, ny, nz;
+            lds_read_xyz_pair(pa, nx, ny, nz);
+            uint32_t j0 = start, j1 = start + 1;
+#pragma nounroll
+            for (int t = 0; t < tmax; t += 2) {
+                lds_wait(nx, ny, nz);
+                const f32x2 dx = qx2 - nx, dy = qy2 - ny, dz = qz2 - nz;
+                pa = min(pa + 24u, pa_last);
+                lds_read_xyz_pair(pa, nx, ny, nz);
+                f32x2 d = dx * dx;
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                const uint32_t k0 = (__float_as_uint(d.x) & ~ORD_MASK) | j0;
+                const uint32_t k1 = (__float_as_uint(d.y) & ~ORD_MASK) | j1;
+                if (j0 < end && k0 < thr) {
+                    wp += 4u * PC_WAVE;
+                    lds_write_u32(wp, k0);
+                }
+                if (j1 < end && k1 < thr) {
+                    wp += 4u * PC_WAVE;
+                    lds_write_u32(wp, k1);
+                }
+                j0 += 2;
+                j1 += 2;
+                if (__any(wp >= wp_full)) drain();
+            }
+            lds_wait(nx, ny, nz);  // retire the last (unused) request
+        }
+        drain();
+        if (!live) continue;
+
+        // ---- stage 2: exact finish --------------------------------------------------------------------
+        const double qv[3] = {qxd, qyd, qzd};
+        bool whole = true;
+        double dmin = INFINITY;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int nlo = max(qc[a] - 1, 0), nhi = min(qc[a] + 1, gp.dim[a] - 1);
+            if (nlo > 0) {
+                whole = false;
+                dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)nlo * gp.cell));
+            }
+            if (nhi < gp.dim[a] - 1) {
+                whole = false;
+                dmin = fmin(dmin, (gp.o[a] + (double)(nhi + 1) * gp.cell) - qv[a]);
+            }
+        }
+        double bound = INFINITY;  // no unscanned point is closer than sqrt(bound)
+        if (!whole) {
+            const double b = dmin - eps;
+            bound = b > 0 ? b * b : 0.0;
+        }
+        // no unlisted candidate of the scanned cells is closer than sqrt(T * (1 - 2^-20))
+        if (L[KS - 1] != KEY_EMPTY) {
+            const double T = (double)__uint_as_float(L[KS - 1] & ~ORD_MASK);
+            if (TileRec<REC>::kRelative) {
+                // keys were measured on coordinates rounded in the block frame
+                const double rt = sqrt(T) * (1.0 - 9.5367431640625e-07) - 4.76837158203125e-07 * bext;
+                bound = fmin(bound, rt > 0.0 ? rt * rt : 0.0);
+            } else {
+                bound = fmin(bound, T * (1.0 - 9.5367431640625e-07));
+            }
+        }
+
+        double dd[KS];
+        uint32_t od[KS];
+        int nsafe = 0, cnt = 0, nvalid = 0;
+        double dmax = 0.0;  // farthest listed candidate: bounds the k-th distance when k are listed
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            dd[s] = INFINITY;
+            od[s] = L[s] & ORD_MASK;
+            if (L[s] != KEY_EMPTY) {
+                double cx, cy, cz;
+                int32_t cid;
+                TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2], cws[od[s]]), cx, cy, cz, cid);
+                const double dx = qxd - cx, dy = qyd - cy, dz = qzd - cz;
+                double d = dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                nvalid++;
+                dmax = fmax(dmax, d);
+                if (d < bound) {
+                    nsafe++;
+                    if (!(r2lim >= 0.0 && !(d < r2lim))) {
+                        dd[s] = d;
+                        cnt++;
+                    }
+                }
+            }
+        }
+        const bool ok = nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim);
+        if (!ok) {
+            float ubf = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
+            if (A.qflag_in) ubf = fminf(ubf, A.qub_arr[qid]);
+            if (A.qflag_out) {
+                A.qflag_out[qid] = 1;
+                A.qub_arr[qid] = ubf;
+            } else {
+                const uint32_t p = atomicAdd(A.flag_count, 1u);
+                if (p < A.flag_cap) {
+                    A.flag_list[p] = (int32_t)spos;
+                    A.flag_ub[p] = ubf;
+                }
+            }
+            continue;
+        }
+        if (A.qflag_in && A.qflag_out) A.qflag_out[qid] = 0;  // answered: later passes skip it
+        // The list is already ordered by the truncated fp32 key, so the exact (d2, index) order
+        // differs from it by a few adjacent transpositions at most: bubble passes until no lane of
+        // the wave swaps (excluded entries carry d2 = +inf and sink to the end).  Original indices
+        // matter only between equal distances and are fetched then (keeps 18 registers free).
+        auto orig_index = [&](uint32_t o) {
+            double x, y, z;
+            int32_t nid;
+            TileRec<REC>::exact(rec, make_float4(0.f, 0.f, 0.f, cws[o]), x, y, z, nid);
+            return nid;
+        };
+#pragma nounroll
+        for (int pass = 0; pass < KS; pass++) {
+            bool swapped = false;
+#pragma unroll
+            for (int s = 0; s + 1 < KS; s++) {
+                const double da = dd[s], db = dd[s + 1];
+                const uint32_t oa = od[s], ob = od[s + 1];
+                const bool gt = da > db;
+                dd[s] = fmin(da, db);
+                dd[s + 1] = fmax(da, db);
+                od[s] = gt ? ob : oa;
+                od[s + 1] = gt ? oa : ob;
+                swapped |= gt;
+            }
+            if (!__any(swapped)) break;
+        }
+        // equal distances (rare): order those neighbours by original index
+        bool ties = false;
+#pragma unroll
+        for (int s = 0; s + 1 < KS; s++) ties |= dd[s] == dd[s + 1] && dd[s] != INFINITY;
+        if (__any(ties)) {
+#pragma nounroll
+            for (int pass = 0; pass < KS; pass++) {
+                bool swapped = false;
+#pragma unroll
+                for (int s = 0; s + 1 < KS; s++) {
+                    const uint32_t oa = od[s], ob = od[s + 1];
+                    bool gt = false;
+                    if (dd[s] == dd[s + 1] && dd[s] != INFINITY) gt = orig_index(oa) > orig_index(ob);
+                    od[s] = gt ? ob : oa;
+                    od[s + 1] = gt ? oa : ob;
+                    swapped |= gt;
+                }
+                if (!__any(swapped)) break;
+            }
+        }
+        cnt = min(cnt, k);
+        if (MODE == M_KNN) {
+            // rows straight from the sorted registers (no second look at the candidates)
+            const int64_t row = (int64_t)qid * k;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                if (s < k) {  // wave-uniform
+                    const bool have = s < cnt;
+                    if (A.out_idx) A.out_idx[row + s] = have ? orig_index(od[s]) : -1;
+                    if (A.out_d2) {
+                        const double d = have ? dd[s] : INFINITY;
+                        if (A.d2_f64)
+                            reinterpret_cast<double *>(A.out_d2)[row + s] = d;
+                        else
+                            reinterpret_cast<float *>(A.out_d2)[row + s] = (float)d;
+                    }
+                }
+            }
+            if (A.out_cnt) A.out_cnt[qid] = cnt;
+            continue;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+            if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
+        emit_result<MODE>(A, (int64_t)qid, cnt,
+                          [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
+                              const uint32_t o = ordbuf[s * PC_WAVE + lane];
+                              TileRec<REC>::exact(rec, make_float4(cxyz[3 * o], cxyz[3 * o + 1], cxyz[3 * o + 2], cws[o]), x, y, z, nid);
+                              const double dx = qxd - x, dy = qyd - y, dz = qzd - z;
+                              d = dx * dx;
+                              d += dy * dy;
+                              d += dz * dz;
+                          });
+    }
+    return 0;
+}
+
+template <typename REC, int KS, int MODE, bool SPLIT>
+__global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Remap so
+    // that each XCD walks one contiguous eighth of the tile sequence: x/y-neighbouring tiles, whose
+    // halos overlap, then hit the same L2 (placement is a speed matter only, never correctness).
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = bid & 7u;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid;
+    const int tx = (int)(t % A.ntile[0]);
+    t /= A.ntile[0];
+    const int ty = (int)(t % A.ntile[1]);
+    const int tz = (int)(t / A.ntile[1]);
+    const int c0[3] = {tx * A.tile[0], ty * A.tile[1], tz * A.tile[2]};  // first cell of the tile
+    const int ext[3] = {A.tile[0], A.tile[1], A.tile[2]};
+    if (!SPLIT) {  // (clouds that fill their box: the tile shape was sized for the LDS capacity)
+        tile_body<REC, KS, MODE>(A, smem, c0, ext, false);
+        return;
+    }
+    // The whole tile first; if its block is too full for LDS, its (up to) eight half-size parts
+    // one after the other: big tiles fill the waves where the cloud is thin without giving up
+    // the dense parts.
+    const int half[3] = {(ext[0] + 1) / 2, (ext[1] + 1) / 2, (ext[2] + 1) / 2};
+    int nsub = 0;
+    for (int sub = -1; sub < nsub; sub++) {
+        int sc0[3], sext[3];
+        bool empty = false;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int hi_part = sub < 0 ? 0 : (sub >> a) & 1;
+            sc0[a] = c0[a] + hi_part * half[a];
+            sext[a] = sub < 0 ? ext[a] : (hi_part ? ext[a] - half[a] : half[a]);
+            empty |= sext[a] <= 0 || sc0[a] >= A.gp.dim[a];
+        }
+        if (empty) continue;
+        const int again = tile_body<REC, KS, MODE>(A, smem, sc0, sext, sub < 0);
+        if (sub < 0) {
+            if (!again) break;
+            nsub = 8;
+        }
+    }
+}
+
+template <typename REC, int KS, bool SPLIT>
+void launch_tile(int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
+    const dim3 grid(nblocks), block(PC_WAVE * nw);
+    switch (mode) {
+        case M_KNN: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_KNN, SPLIT>), grid, block, lds, st, A); break;
+        case M_SOR: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_SOR, SPLIT>), grid, block, lds, st, A); break;
+        case M_NORMALS: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NORMALS, SPLIT>), grid, block, lds, st, A); break;
+        case M_NNDIST: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_NNDIST, SPLIT>), grid, block, lds, st, A); break;
+        case M_ALL: hipLaunchKernelGGL((k_tile_scan<REC, KS, M_ALL, SPLIT>), grid, block, lds, st, A); break;
+        default: break;
+    }
+}
+
+template <typename REC, bool SPLIT>
+void launch_tile_ks(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A) {
+    switch (ks) {
+        case 4: launch_tile<REC, 4, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 10: launch_tile<REC, 10, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 18: launch_tile<REC, 18, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 22: launch_tile<REC, 22, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        default: launch_tile<REC, 34, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+    }
+}
+
+}  // namespace
