@@ -1,17 +1,21 @@
-// Tile-cooperative exact kNN (self-queries, k <= 32; fp32 and fp64 grids).
+// Tile-cooperative exact kNN (k <= 32; fp32 and fp64 grids; the grid's own points or external
+// queries binned into the grid).  This file: the host side (tile shapes, occupied-tile lists, the
+// passes over the index levels); the kernel lives in pc_knn_tile_kernel.h.
 //
-// One wave owns one tile of cells.  The tile's candidate block (the tile plus a one-cell halo;
-// its (y,z) rows are contiguous point ranges) is staged once into LDS; each lane then answers
-// one query of the tile and every lane walks the SAME candidate sequence, so a candidate is one
-// broadcast ds_read_b128.  Selection is two-stage:
+// A workgroup of 1-4 waves owns one tile of cells.  The tile's candidate block (the tile plus a
+// one-cell halo; its (y,z) rows are contiguous point ranges) is staged once into LDS; each lane
+// then answers one query of the tile, walking its own 3x3x3 cells in lock-step with its wave.
+// Selection is two-stage:
 //   1. fp32 filter: key = (fp32 d2 bits with the low ORD_BITS cleared) | candidate ordinal.
-//      Keys are unique u32, so a sorted list of KS keys per lane is maintained in registers
-//      with one v_med3_u32 per slot per candidate:  L[s] = med3(L[s-1], key, L[s]).
+//      Keys are unique u32.  A sorted list of KS = k + 2 keys per lane lives in registers
+//      (L[s] = med3(L[s-1], key, L[s]), one v_med3_u32 per slot), but only keys below the list's
+//      last entry can change it: those are parked in a lane-private LDS column and inserted in
+//      batches.
 //   2. exact finish: the KS survivors are re-measured in fp64 in the reference's operation
 //      order, ranked by (d2, original index), and the result is accepted only if at least k of
 //      them lie strictly below a bound that no unlisted candidate and no unscanned point can
 //      beat.  Queries that cannot be certified (sparse surroundings, heavy ties, over-full
-//      tiles) are appended to a list that the one-query-per-lane fp64 scan answers afterwards.
+//      tiles) are flagged for the next coarser index level, then for the wave-per-query kernel.
 // The consumers (mean distance, normal, ...) run on the certified list while the candidates
 // are still in LDS.  HBM traffic per query is therefore the algorithmic minimum plus the halo
 // re-reads served by L2.
