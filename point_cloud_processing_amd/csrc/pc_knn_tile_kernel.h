@@ -517,6 +517,35 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         if (MODE == M_KNN) {
             // rows straight from the sorted registers (no second look at the candidates)
             const int64_t row = (int64_t)qid * k;
+            if ((k & 3) == 0) {  // (uniform) rows of 16-byte groups: vector stores
+#pragma unroll
+                for (int s = 0; s + 3 < KS; s += 4) {
+                    if (s < k) {
+                        if (A.out_idx) {
+                            int4 v;
+                            v.x = s < cnt ? orig_index(od[s]) : -1;
+                            v.y = s + 1 < cnt ? orig_index(od[s + 1]) : -1;
+                            v.z = s + 2 < cnt ? orig_index(od[s + 2]) : -1;
+                            v.w = s + 3 < cnt ? orig_index(od[s + 3]) : -1;
+                            *reinterpret_cast<int4 *>(A.out_idx + row + s) = v;
+                        }
+                        if (A.out_d2) {
+                            const double d0 = s < cnt ? dd[s] : INFINITY, d1 = s + 1 < cnt ? dd[s + 1] : INFINITY,
+                                         d2v = s + 2 < cnt ? dd[s + 2] : INFINITY, d3 = s + 3 < cnt ? dd[s + 3] : INFINITY;
+                            if (A.d2_f64) {
+                                double *o = reinterpret_cast<double *>(A.out_d2) + row + s;
+                                *reinterpret_cast<double2 *>(o) = make_double2(d0, d1);
+                                *reinterpret_cast<double2 *>(o + 2) = make_double2(d2v, d3);
+                            } else {
+                                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(A.out_d2) + row + s) =
+                                    make_float4((float)d0, (float)d1, (float)d2v, (float)d3);
+                            }
+                        }
+                    }
+                }
+                if (A.out_cnt) A.out_cnt[qid] = cnt;
+                continue;
+            }
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 if (s < k) {  // wave-uniform
