@@ -269,10 +269,11 @@ __device__ inline void fast_eigen3x3(const double cov[6], double out[3]) {
 
 // ---- per-query consumers -------------------------------------------------------------------------
 // NB(s, d2, x, y, z, idx) yields the s-th nearest neighbour (ascending (d2, idx)) of this query.
-template <int MODE, typename NB>
+// ONLY_NORMALS: the caller has written the rows / mean distance itself.
+template <int MODE, bool ONLY_NORMALS = false, typename NB>
 __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, NB nb) {
     const int k = A.k;
-    if ((MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
+    if (!ONLY_NORMALS && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
         for (int s = 0; s < k; s++) {
             int32_t id = -1;
             double d = INFINITY, x, y, z;
@@ -287,7 +288,7 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
         }
         if (A.out_cnt) A.out_cnt[out_row] = cnt;
     }
-    if (MODE == M_SOR || (MODE == M_ALL && A.out_f64)) {
+    if (!ONLY_NORMALS && (MODE == M_SOR || (MODE == M_ALL && A.out_f64))) {
         double m = -1.0;
         if (cnt > 0) {
             double sum = 0.0;
@@ -301,7 +302,7 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
         }
         A.out_f64[out_row] = m;
     }
-    if (MODE == M_NNDIST) {
+    if (!ONLY_NORMALS && MODE == M_NNDIST) {
         double d = 0.0, x, y, z;
         int32_t id;
         if (cnt > 1) {

@@ -514,7 +514,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
         }
         cnt = min(cnt, k);
-        if (MODE == M_KNN) {
+        if ((MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
             // rows straight from the sorted registers (no second look at the candidates)
             const int64_t row = (int64_t)qid * k;
             if ((k & 3) == 0) {  // (uniform) rows of 16-byte groups: vector stores
@@ -543,30 +543,42 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                         }
                     }
                 }
-                if (A.out_cnt) A.out_cnt[qid] = cnt;
-                continue;
-            }
+            } else {
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                if (s < k) {  // wave-uniform
-                    const bool have = s < cnt;
-                    if (A.out_idx) A.out_idx[row + s] = have ? orig_index(od[s]) : -1;
-                    if (A.out_d2) {
-                        const double d = have ? dd[s] : INFINITY;
-                        if (A.d2_f64)
-                            reinterpret_cast<double *>(A.out_d2)[row + s] = d;
-                        else
-                            reinterpret_cast<float *>(A.out_d2)[row + s] = (float)d;
+                for (int s = 0; s < KS; s++) {
+                    if (s < k) {  // wave-uniform
+                        const bool have = s < cnt;
+                        if (A.out_idx) A.out_idx[row + s] = have ? orig_index(od[s]) : -1;
+                        if (A.out_d2) {
+                            const double d = have ? dd[s] : INFINITY;
+                            if (A.d2_f64)
+                                reinterpret_cast<double *>(A.out_d2)[row + s] = d;
+                            else
+                                reinterpret_cast<float *>(A.out_d2)[row + s] = (float)d;
+                        }
                     }
                 }
             }
             if (A.out_cnt) A.out_cnt[qid] = cnt;
+        }
+        if (MODE == M_KNN) continue;
+        if (MODE == M_SOR || (MODE == M_ALL && A.out_f64)) {
+            // mean neighbour distance, summed nearest first like the generic consumer
+            double sum = 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+                if (s < cnt) sum += sqrt(dd[s]);
+            A.out_f64[qid] = cnt > 0 ? sum / (double)cnt : -1.0;
+            if (MODE == M_SOR) continue;
+        }
+        if (MODE == M_NNDIST) {
+            A.out_f64[qid] = cnt > 1 ? sqrt(dd[1]) : 0.0;
             continue;
         }
 #pragma unroll
         for (int s = 0; s < KS; s++)
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
-        emit_result<MODE>(A, (int64_t)qid, cnt,
+        emit_result<MODE, true>(A, (int64_t)qid, cnt,
                           [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
                               const uint32_t o = ordbuf[s * PC_WAVE + lane];
                               TileRec<REC>::exact(rec, make_float4(cxyz[3 * o], cxyz[3 * o + 1], cxyz[3 * o + 2], cws[o]), x, y, z, nid);
