@@ -167,6 +167,14 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
                         best[2] = tz;
                     }
                 }
+        if (const char *e = getenv("PC_AMD_TILE")) {  // tuning knob: "tx,ty,tz"
+            int v[3];
+            if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] >= 1 && v[0] + 2 <= MAX_NX && v[1] >= 1 && v[2] >= 1 &&
+                (v[1] + 2) * (v[2] + 2) <= MAX_ROWS) {
+                for (int a = 0; a < 3; a++) best[a] = std::min(v[a], std::max(1, (int)g->gp.dim[a]));
+                best_pop = occ * best[0] * best[1] * best[2];
+            }
+        }
         // no more waves than the expected population needs
         waves = std::min(waves, std::max(1, (int)ceil((best_pop + 1.5 * sqrt(std::max(best_pop, 0.0))) / PC_WAVE)));
         expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2);
