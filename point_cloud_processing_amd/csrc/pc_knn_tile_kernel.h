@@ -514,8 +514,10 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
         }
         cnt = min(cnt, k);
-        if ((MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
-            // rows straight from the sorted registers (no second look at the candidates)
+        // Rows and mean distance straight from the sorted registers (no second look at the candidates);
+        // the long lists of k > 20 keep fewer registers alive by going through the generic consumer.
+        constexpr bool DIRECT = KS <= 22;
+        if (DIRECT && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
             const int64_t row = (int64_t)qid * k;
             if ((k & 3) == 0) {  // (uniform) rows of 16-byte groups: vector stores
 #pragma unroll
@@ -561,8 +563,8 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
             if (A.out_cnt) A.out_cnt[qid] = cnt;
         }
-        if (MODE == M_KNN) continue;
-        if (MODE == M_SOR || (MODE == M_ALL && A.out_f64)) {
+        if (DIRECT && MODE == M_KNN) continue;
+        if (DIRECT && (MODE == M_SOR || (MODE == M_ALL && A.out_f64))) {
             // mean neighbour distance, summed nearest first like the generic consumer
             double sum = 0.0;
 #pragma unroll
@@ -578,7 +580,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
 #pragma unroll
         for (int s = 0; s < KS; s++)
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
-        emit_result<MODE, true>(A, (int64_t)qid, cnt,
+        emit_result<MODE, DIRECT>(A, (int64_t)qid, cnt,
                           [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
                               const uint32_t o = ordbuf[s * PC_WAVE + lane];
                               TileRec<REC>::exact(rec, make_float4(cxyz[3 * o], cxyz[3 * o + 1], cxyz[3 * o + 2], cws[o]), x, y, z, nid);
