@@ -40,6 +40,17 @@ __device__ inline uint32_t lds_read_u32(uint32_t addr) {
 __device__ inline void lds_write_u32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v)); }
 __device__ inline void lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
 
+// Maximum over the wave (uniform result): butterfly inside each row of 16 lanes with DPP
+// (pairs, quads, half rows, rows: no LDS traffic), then the four row results through SGPRs.
+__device__ inline int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 template <int KS>
 __device__ inline void list_insert(uint32_t (&L)[KS], uint32_t key) {
 #pragma unroll
@@ -341,12 +352,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             seg_max[seg] = (int)ln;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int seg = 0; seg < 9; seg++) seg_max[seg] = max(seg_max[seg], __shfl_xor(seg_max[seg], o, 64));
-        }
-#pragma unroll
-        for (int seg = 0; seg < 9; seg++) seg_max[seg] = __builtin_amdgcn_readfirstlane(seg_max[seg]);
+        for (int seg = 0; seg < 9; seg++) seg_max[seg] = wave_max_i32(seg_max[seg]);
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         const uint32_t cand_a = (uint32_t)(uintptr_t)(const lds_f32 *)cxyz;  // LDS byte address
         const uint32_t pa_last = cand_a + 12u * (ncand - 1);
