@@ -1,0 +1,267 @@
+// Exact kNN for a LIST of open queries of one index level: the coarser passes of a multi-level
+// index, where only a few points per tile are still unanswered and one workgroup per tile would run
+// nearly empty waves.  The open queries, in the level's cell order, are dealt 64 to a wave; lane =
+// query.  Nothing is staged: a lane reads the records of its own 3x3x3 cells from global memory (L2
+// serves the neighbours' re-reads), in lock-step with its wave over the nine (y, z) row segments.
+//   pass A: the k-th smallest fp32-rounded exact distance.  Every squared distance is computed in
+//           fp64 in the reference's operation order; rounding it to fp32 is monotone, so a sorted
+//           register list of those u32 keys (one v_med3_u32 per slot and candidate) yields a
+//           threshold that no true neighbour exceeds.
+//   pass B: the same candidates again; those at or below the threshold (k of them, plus rounding
+//           ties) go with their fp64 distance into a lane-private LDS column, are ordered by
+//           (d2, original index) and certified against the distance to the unscanned cells exactly
+//           like in the tile kernel.  Uncertified queries keep their flag for the next level.
+#include "pc_knn_dev.h"
+
+namespace {
+
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+constexpr int COL_EXTRA = 6;  // room for rounding ties beyond the list length
+
+template <int KS>
+__device__ inline void key_insert(uint32_t (&L)[KS], uint32_t key) {
+#pragma unroll
+    for (int s = KS - 1; s > 0; s--) asm("v_med3_u32 %0, %1, %2, %0" : "+v"(L[s]) : "v"(L[s - 1]), "v"(key));
+    asm("v_min_u32 %0, %0, %1" : "+v"(L[0]) : "v"(key));
+}
+
+__device__ inline int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <typename REC, int KS, int MODE>
+__global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_t *__restrict__ list, uint32_t count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CB = KS + COL_EXTRA;
+    double *bd = reinterpret_cast<double *>(smem);              // [CB][64] exact squared distances
+    uint32_t *bp = reinterpret_cast<uint32_t *>(bd + CB * PC_WAVE);  // [CB][64] sorted positions
+    const int lane = threadIdx.x;
+    const int k = A.k;
+    const GridParams &gp = A.gp;
+    const REC *rec = reinterpret_cast<const REC *>(A.rec);
+    const REC *qsrc = A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec;
+    const uint32_t qi = blockIdx.x * PC_WAVE + lane;
+    const bool active = qi < count;
+    double qx = 0.0, qy = 0.0, qz = 0.0;
+    int32_t qid = 0;
+    if (active) RecTraits<REC>::load(qsrc + list[qi], qx, qy, qz, qid);
+    const double qv[3] = {qx, qy, qz};
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double t = floor((qv[a] - gp.o[a]) * gp.s);
+        c[a] = !(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)t);
+    }
+    const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, gp.dim[0] - 1);
+    // the nine row segments of this lane (own row first) and the wave-wide longest of each
+    constexpr int SEG_DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+    constexpr int SEG_DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+    uint32_t jb[9], jn[9];
+    int tmax[9];
+#pragma unroll
+    for (int seg = 0; seg < 9; seg++) {
+        const int y = c[1] + SEG_DY[seg], z = c[2] + SEG_DZ[seg];
+        jb[seg] = 0;
+        jn[seg] = 0;
+        if (active && y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2]) {
+            const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+            jb[seg] = cell_begin(A.ci, row + x0);
+            jn[seg] = cell_begin(A.ci, row + x1 + 1) - jb[seg];
+        }
+    }
+    // A query amid more candidates than a tile pass would stage is not worth a lane here either: it
+    // keeps its flag (coarser cells are fuller still, so it ends with the wave-per-query kernel).
+    uint32_t total = 0;
+#pragma unroll
+    for (int seg = 0; seg < 9; seg++) total += jn[seg];
+    const bool crowded = total > (uint32_t)A.cand_cap;
+    if (crowded) {
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) jn[seg] = 0;
+    }
+#pragma unroll
+    for (int seg = 0; seg < 9; seg++) tmax[seg] = wave_max((int)jn[seg]);
+
+    auto dist2 = [&](uint32_t j, int32_t &pid) {
+        double px, py, pz;
+        RecTraits<REC>::load(rec + j, px, py, pz, pid);
+        const double dx = qx - px, dy = qy - py, dz = qz - pz;
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        return d;
+    };
+
+    // ---- pass A: threshold ---------------------------------------------------------------------------
+    uint32_t L[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) L[s] = KEY_NONE;
+#pragma unroll
+    for (int seg = 0; seg < 9; seg++) {
+#pragma nounroll
+        for (int t = 0; t < tmax[seg]; t++) {
+            uint32_t key = KEY_NONE;
+            if ((uint32_t)t < jn[seg]) {
+                int32_t pid;
+                key = __float_as_uint((float)dist2(jb[seg] + t, pid));
+            }
+            key_insert<KS>(L, key);
+        }
+    }
+    // everything at or below the k-th smallest rounded distance holds the k nearest (all candidates
+    // if the cells hold fewer than k)
+    const uint32_t thr = (total >= (uint32_t)k) ? L[k - 1] : 0x7F800000u;
+
+    // ---- pass B: collect, order, certify ----------------------------------------------------------------
+    int n = 0;
+    bool overflow = false;
+#pragma unroll
+    for (int seg = 0; seg < 9; seg++) {
+#pragma nounroll
+        for (int t = 0; t < tmax[seg]; t++) {
+            if ((uint32_t)t < jn[seg]) {
+                int32_t pid;
+                const uint32_t j = jb[seg] + t;
+                const double d = dist2(j, pid);
+                if (__float_as_uint((float)d) <= thr) {
+                    if (n < CB) {
+                        // insertion by (d2, original index); ties fetch the index of the stored entry
+                        int p = n;
+                        while (p > 0) {
+                            const double dp = bd[(p - 1) * PC_WAVE + lane];
+                            if (dp < d) break;
+                            const uint32_t pp = bp[(p - 1) * PC_WAVE + lane];
+                            if (dp == d) {
+                                double tx, ty, tz;
+                                int32_t tid;
+                                RecTraits<REC>::load(rec + pp, tx, ty, tz, tid);
+                                if (tid < pid) break;
+                            }
+                            bd[p * PC_WAVE + lane] = dp;
+                            bp[p * PC_WAVE + lane] = pp;
+                            p--;
+                        }
+                        bd[p * PC_WAVE + lane] = d;
+                        bp[p * PC_WAVE + lane] = j;
+                        n++;
+                    } else {
+                        overflow = true;  // more rounding ties than the column holds
+                    }
+                }
+            }
+        }
+    }
+    if (!active || crowded) return;
+
+    // no unscanned point is closer than sqrt(bound)
+    bool whole = true;
+    double dmin = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int nlo = max(c[a] - 1, 0), nhi = min(c[a] + 1, gp.dim[a] - 1);
+        if (nlo > 0) {
+            whole = false;
+            dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)nlo * gp.cell));
+        }
+        if (nhi < gp.dim[a] - 1) {
+            whole = false;
+            dmin = fmin(dmin, (gp.o[a] + (double)(nhi + 1) * gp.cell) - qv[a]);
+        }
+    }
+    double bound = INFINITY;
+    if (!whole) {
+        const double b = dmin - 1e-7 * gp.cell;
+        bound = b > 0 ? b * b : 0.0;
+    }
+    const double r2lim = A.radius2;
+    int nsafe = 0, cnt = 0;
+    for (int s = 0; s < n; s++) {
+        const double d = bd[s * PC_WAVE + lane];
+        if (d < bound) {
+            nsafe++;
+            if (!(r2lim >= 0.0 && !(d < r2lim))) cnt++;  // (ascending: the accepted ones are a prefix)
+        }
+    }
+    const bool ok = !overflow && (nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim));
+    if (!ok) {
+        if (n >= k && !overflow) A.qub_arr[qid] = fminf(A.qub_arr[qid], (float)(bd[(k - 1) * PC_WAVE + lane] * (1.0 + 1e-6)));
+        return;  // stays flagged
+    }
+    A.qflag_out[qid] = 0;
+    cnt = min(cnt, k);
+    emit_result<MODE>(A, (int64_t)qid, cnt, [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
+        d = bd[s * PC_WAVE + lane];
+        RecTraits<REC>::load(rec + bp[s * PC_WAVE + lane], x, y, z, id);
+    });
+}
+
+template <typename REC, int KS>
+void launch_mode(int mode, unsigned nb, size_t lds, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count) {
+    switch (mode) {
+        case M_KNN: hipLaunchKernelGGL((k_batch_scan<REC, KS, M_KNN>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count); break;
+        case M_SOR: hipLaunchKernelGGL((k_batch_scan<REC, KS, M_SOR>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count); break;
+        case M_NORMALS: hipLaunchKernelGGL((k_batch_scan<REC, KS, M_NORMALS>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count); break;
+        case M_NNDIST: hipLaunchKernelGGL((k_batch_scan<REC, KS, M_NNDIST>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count); break;
+        case M_ALL: hipLaunchKernelGGL((k_batch_scan<REC, KS, M_ALL>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count); break;
+        default: break;
+    }
+}
+
+template <typename REC>
+void launch_ks(int ks, int mode, unsigned nb, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count) {
+    const size_t lds = (sizeof(double) + sizeof(uint32_t)) * PC_WAVE * (size_t)(ks + COL_EXTRA);
+    switch (ks) {
+        case 4: launch_mode<REC, 4>(mode, nb, lds, st, A, list, count); break;
+        case 10: launch_mode<REC, 10>(mode, nb, lds, st, A, list, count); break;
+        case 18: launch_mode<REC, 18>(mode, nb, lds, st, A, list, count); break;
+        case 22: launch_mode<REC, 22>(mode, nb, lds, st, A, list, count); break;
+        default: launch_mode<REC, 34>(mode, nb, lds, st, A, list, count); break;
+    }
+}
+
+// flags[s] = 1 where the record at sorted position s (of this level) belongs to an open query
+template <typename REC>
+__global__ __launch_bounds__(256) void k_open_flags(const REC *__restrict__ rec, int64_t n, const uint8_t *__restrict__ qflag,
+                                                     uint8_t *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    double x, y, z;
+    int32_t id;
+    RecTraits<REC>::load(rec + s, x, y, z, id);
+    out[s] = qflag[id];
+}
+
+}  // namespace
+
+// The open queries (qflag set) of the level whose records are `qsrc` (n of them, the level's own
+// points or external queries binned into it), as ascending sorted positions in list_out; *count on
+// the host (synchronises).
+int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, const uint8_t *qflag, int32_t *list_out,
+                       int64_t *count, hipStream_t st) {
+    *count = 0;
+    if (n <= 0) return PC_OK;
+    Scratch f(ctx, (size_t)n);
+    if (!f.ok()) return pc_fail(ctx, PC_NOMEM, "open-query flags");
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_open_flags<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)qsrc, n, qflag, f.as<uint8_t>());
+    else
+        hipLaunchKernelGGL(k_open_flags<Rec64>, dim3(nb), dim3(256), 0, st, (const Rec64 *)qsrc, n, qflag, f.as<uint8_t>());
+    PC_HIP(hipGetLastError());
+    return pc_compact_flags(ctx, f.as<uint8_t>(), n, list_out, count, st);
+}
+
+// One level pass over the listed open queries (A describes the level; A.qflag_out / A.qub_arr are set).
+int pc_launch_batch_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
+                         hipStream_t st) {
+    if (count <= 0) return PC_OK;
+    const unsigned nb = (unsigned)((count + PC_WAVE - 1) / PC_WAVE);
+    if (dtype == PC_F32)
+        launch_ks<Rec32>(ks, mode, nb, st, A, list, (uint32_t)count);
+    else
+        launch_ks<Rec64>(ks, mode, nb, st, A, list, (uint32_t)count);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}

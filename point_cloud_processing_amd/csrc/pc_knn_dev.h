@@ -370,5 +370,11 @@ void pc_tile_launch_f32_split(int ks, int mode, unsigned nblocks, int nw, size_t
 void pc_tile_launch_f64(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
 void pc_tile_launch_f64_split(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
 
+// pc_knn_batch.hip: a level pass over the list of still-open queries, 64 to a wave
+int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, const uint8_t *qflag, int32_t *list_out,
+                       int64_t *count, hipStream_t st);
+int pc_launch_batch_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
+                         hipStream_t st);
+
 // pc_knn_wave.hip: one wave per listed query (A.qlist / A.qub / A.qcount).
 int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A, hipStream_t st);

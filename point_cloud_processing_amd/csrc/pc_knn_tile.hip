@@ -266,7 +266,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // block returns to the pool when this function ends, which is safe because everything that
     // touches it is ordered on `st`
     const size_t npt = A.qrec ? (size_t)A.nq : (size_t)g->n;
-    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (nlv > 1 ? 5 * npt + 64 : 0));
+    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (nlv > 1 ? 9 * npt + 128 : 0));
     if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run lists");
     A.flag_count = flags.as<uint32_t>();
     A.flag2_count = A.flag_count + 16;
@@ -275,11 +275,16 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     A.flag2_list = A.flag_list + 2 * A.nq;
     PC_HIP(hipMemsetAsync(A.flag_count, 0, 256, st));
     uint8_t *qflag = nullptr;
+    int32_t *open_list = nullptr;
     if (nlv > 1) {
         A.qub_arr = reinterpret_cast<float *>(A.flag2_list + A.nq);
-        qflag = reinterpret_cast<uint8_t *>(A.qub_arr + npt);
+        open_list = reinterpret_cast<int32_t *>(A.qub_arr + npt);
+        qflag = reinterpret_cast<uint8_t *>(open_list + npt);
         PC_HIP(hipMemsetAsync(qflag, 0, npt, st));
     }
+    // coarser levels: a tile pass per occupied tile, or the open queries dealt 64 to a wave
+    const bool batch_passes = getenv("PC_AMD_NO_BATCH") == nullptr;
+    int64_t open_prev = 0;  // queries still open after the previous pass
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
     // external queries arrive binned into level 0; a coarser level bins them again into its own cells
     const void *qrec0 = A.qrec;
@@ -305,7 +310,11 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         }
         A.tile_list = l->tile_list;
         if (l->tile_list) nt = l->tile_count;
-        if (A.qrec && l->tile_list) {
+        // A coarser level whose open queries are spread thinly over its tiles (fewer than three per tile;
+        // external queries always) is answered from the list of open queries, 64 to a wave, instead of a
+        // workgroup per tile (measured: a gain for the short lists of k <= 16, a loss for k >= 20).
+        const bool batch = i > 0 && batch_passes && ks <= 18 && (A.qrec || open_prev < 3 * std::max<int64_t>(nt, 1));
+        if (A.qrec && l->tile_list && !batch) {
             // the grid's list names the tiles that hold POINTS; external queries need the tiles that hold
             // queries (the block returns to the pool right away: everything using it is ordered on st)
             uint32_t *ql = nullptr;
@@ -316,26 +325,33 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.cand_cap = l->tile_cap;
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
-        if (nt <= 0) continue;
-        const int nw = std::max(1, l->tile_waves);
-        if (getenv("PC_AMD_DEBUG"))
-            fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],
-                    l->tile[2], l->tile_cap, nw, (long long)nt);
-        const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
-                           sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
-                           nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
-        if (g->dtype == PC_F32) {
-            if (l->uneven)
-                pc_tile_launch_f32_split(ks, mode, (unsigned)nt, nw, lds, st, A);
-            else
-                pc_tile_launch_f32(ks, mode, (unsigned)nt, nw, lds, st, A);
+        if (batch) {
+            int64_t nopen = 0;
+            PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, open_list, &nopen, st));
+            if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass %d: %lld open queries\n", i, (long long)nopen);
+            PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
         } else {
-            if (l->uneven)
-                pc_tile_launch_f64_split(ks, mode, (unsigned)nt, nw, lds, st, A);
-            else
-                pc_tile_launch_f64(ks, mode, (unsigned)nt, nw, lds, st, A);
+            if (nt <= 0) continue;
+            const int nw = std::max(1, l->tile_waves);
+            if (getenv("PC_AMD_DEBUG"))
+                fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],
+                        l->tile[2], l->tile_cap, nw, (long long)nt);
+            const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+                               sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
+                               nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
+            if (g->dtype == PC_F32) {
+                if (l->uneven)
+                    pc_tile_launch_f32_split(ks, mode, (unsigned)nt, nw, lds, st, A);
+                else
+                    pc_tile_launch_f32(ks, mode, (unsigned)nt, nw, lds, st, A);
+            } else {
+                if (l->uneven)
+                    pc_tile_launch_f64_split(ks, mode, (unsigned)nt, nw, lds, st, A);
+                else
+                    pc_tile_launch_f64(ks, mode, (unsigned)nt, nw, lds, st, A);
+            }
+            PC_HIP(hipGetLastError());
         }
-        PC_HIP(hipGetLastError());
         if (qflag) {
             // how many points are still open decides whether another (coarser) pass is worth it
             int64_t open = 0;
@@ -344,6 +360,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                 fprintf(stderr, "[pc_amd]   level %d: cell %.4g dims %dx%dx%d tile %dx%dx%d cap %d tiles %lld sparse %d -> open %lld\n",
                         i, l->gp.cell, l->gp.dim[0], l->gp.dim[1], l->gp.dim[2], l->tile[0], l->tile[1], l->tile[2],
                         l->tile_cap, (long long)nt, l->keys != nullptr, (long long)open);
+            open_prev = open;
             if (open < std::max<int64_t>(2048, A.nq / 200)) break;
         }
     }
