@@ -71,3 +71,22 @@ def test_scan_paths_agree(hip, oracle, monkeypatch):
     monkeypatch.setenv("PC_AMD_EXACT_SCAN_ONLY", "1")
     b = hip.knn(p, None, 20, -1.0, {})
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("k", [1, 5, 16])
+def test_level_passes_agree(hip, oracle, monkeypatch, k):
+    """Coarser index levels answered from the open-query list (64 to a wave) or by tile passes, and the
+    exact scan alone: three routes, one answer -- on a cloud whose density spans orders of magnitude,
+    for the cloud's own points and for external queries."""
+    p = D.gaussian_clusters(300_000, 21)
+    rng = np.random.default_rng(22)
+    q = (p[rng.permutation(len(p))[:60_000]] + rng.normal(0, 0.01, (60_000, 3))).astype(np.float32).astype(np.float64)
+    a_self, a_ext = hip.knn(p, None, k, -1.0, {}), hip.knn(p, q, k, -1.0, {})
+    monkeypatch.setenv("PC_AMD_NO_BATCH", "1")
+    b_self, b_ext = hip.knn(p, None, k, -1.0, {}), hip.knn(p, q, k, -1.0, {})
+    assert all(np.array_equal(x, y) for x, y in zip(a_self, b_self))
+    assert all(np.array_equal(x, y) for x, y in zip(a_ext, b_ext))
+    ridx, rd2, rcnt = oracle.knn(p, q, k)
+    assert np.array_equal(a_ext[0], ridx) and np.array_equal(a_ext[1], rd2) and np.array_equal(a_ext[2], rcnt)
+    ridx, rd2, rcnt = oracle.Grid(p).knn_self(k)
+    assert np.array_equal(a_self[0], ridx) and np.array_equal(a_self[1], rd2)
