@@ -10,6 +10,8 @@ namespace {
 
 constexpr int SCAP = 512;  // survivors one query may hold in LDS
 
+constexpr int ROW_CACHE = 256;
+
 template <typename REC, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
     __shared__ double sv_d[SCAP];
@@ -17,6 +19,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
     __shared__ int32_t sv_id[SCAP];
     __shared__ double res_d[PC_MAX_K];
     __shared__ uint32_t res_pos[PC_MAX_K];
+    __shared__ uint32_t row_b[ROW_CACHE], row_e[ROW_CACHE];  // record range of each block row
     const int lane = threadIdx.x;
     const REC *rec0 = reinterpret_cast<const REC *>(A.rec);
     const int k = A.k;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             const REC *rec = reinterpret_cast<const REC *>(A.lv[lvl].rec);
             const CellIndex ci = A.lv[lvl].ci;
             const bool last_level = lvl == A.nlv - 1;
-            int lo[3], hi[3];
+            int lo[3], hi[3], cc[3];
             bool whole = true;
             double dmin = INFINITY;
 #pragma unroll
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 const double t = floor((qv[a] - gp.o[a]) * gp.s);
                 const int c = __builtin_amdgcn_readfirstlane(
                     !(t > 0.0) ? 0 : (t >= (double)gp.dim[a] ? gp.dim[a] - 1 : (int)t));
+                cc[a] = c;
                 lo[a] = max(c - R, 0);
                 hi[a] = min(c + R, gp.dim[a] - 1);
                 if (lo[a] > 0) {
@@ -68,8 +72,14 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             uint32_t total = 0;
             for (int r = lane; r < nrows; r += PC_WAVE) {
                 const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
-                total += cell_begin(ci, row + hi[0] + 1) - cell_begin(ci, row + lo[0]);
+                const uint32_t b = cell_begin(ci, row + lo[0]), e = cell_begin(ci, row + hi[0] + 1);
+                total += e - b;
+                if (r < ROW_CACHE) {  // kept for the scan below: the searches of all rows overlap here
+                    row_b[r] = b;
+                    row_e[r] = e;
+                }
             }
+            __syncthreads();
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
             total = __builtin_amdgcn_readfirstlane(total);
@@ -119,13 +129,22 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 };
                 uint32_t m = 0;
                 bool overflow = false;  // more equal-distance survivors than LDS holds
-                for (int r = 0; r < nrows && !overflow; r++) {
+                // the query's own row first: its nearest points give a tight bound at the first thinning
+                const int rc = (cc[1] - lo[1]) + nry * (cc[2] - lo[2]);
+                for (int ri = 0; ri < nrows && !overflow; ri++) {
+                    const int r = ri + rc < nrows ? ri + rc : ri + rc - nrows;
                     const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
-                    // sparse index: lanes 0 and 1 search, the wave shares the two results
-                    uint32_t jv = 0;
-                    if (lane < 2) jv = cell_begin(ci, lane == 0 ? row + lo[0] : row + hi[0] + 1);
-                    const uint32_t jb = __builtin_amdgcn_readfirstlane(__shfl(jv, 0, 64)),
-                                   je = __builtin_amdgcn_readfirstlane(__shfl(jv, 1, 64));
+                    uint32_t jb, je;
+                    if (r < ROW_CACHE) {
+                        jb = row_b[r];
+                        je = row_e[r];
+                    } else {
+                        // sparse index: lanes 0 and 1 search, the wave shares the two results
+                        uint32_t jv = 0;
+                        if (lane < 2) jv = cell_begin(ci, lane == 0 ? row + lo[0] : row + hi[0] + 1);
+                        jb = __builtin_amdgcn_readfirstlane(__shfl(jv, 0, 64));
+                        je = __builtin_amdgcn_readfirstlane(__shfl(jv, 1, 64));
+                    }
                     for (uint32_t j0 = jb; j0 < je; j0 += PC_WAVE) {
                         if (m > SCAP - PC_WAVE) {  // wave-uniform: make room before the next 64 candidates
                             __syncthreads();
