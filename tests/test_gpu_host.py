@@ -21,7 +21,9 @@ def test_normalize_preprocess_radii(oracle):
     assert np.array_equal(np.asarray(proc.points), vp)
     radius = 0.02 * (vp.max(0) - vp.min(0)).max()
     rn = oracle.normals(vp, 30, radius)
-    assert np.abs(np.asarray(proc.normals) - rn).max() < 1e-6
+    got = np.asarray(proc.normals)  # oriented by preprocess: the oracle's lines, outward signs
+    assert np.minimum(np.abs(got - rn).max(1), np.abs(got + rn).max(1)).max() < 1e-6
+    assert (np.einsum("ij,ij->i", got, vp - vp.mean(0)) > 0).mean() > 0.999
     radii = estimate_bpa_radii(proc)
     base = 1.5 * oracle.nn_distance(vp).mean()
     np.testing.assert_allclose(radii, [base, 2 * base, 3 * base], rtol=1e-13)
