@@ -46,7 +46,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     const bool active = qi < count;
     double qx = 0.0, qy = 0.0, qz = 0.0;
     int32_t qid = 0;
-    if (active) RecTraits<REC>::load(qsrc + list[qi], qx, qy, qz, qid);
+    // (no list: every sorted position of the caller's range is a query -- the first pass of a thin cloud)
+    if (active) RecTraits<REC>::load(qsrc + (list ? (int64_t)list[qi] : A.s_begin + (int64_t)qi), qx, qy, qz, qid);
     const double qv[3] = {qx, qy, qz};
     int c[3];
 #pragma unroll
@@ -153,7 +154,14 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
             }
         }
     }
-    if (!active || crowded) return;
+    if (!active) return;
+    if (crowded) {
+        if (!A.qflag_in) {  // first pass: flags and bounds are not initialised yet
+            A.qflag_out[qid] = 1;
+            A.qub_arr[qid] = INFINITY;
+        }
+        return;
+    }
 
     // no unscanned point is closer than sqrt(bound)
     bool whole = true;
@@ -186,8 +194,10 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     }
     const bool ok = !overflow && (nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim));
     if (!ok) {
-        if (n >= k && !overflow) A.qub_arr[qid] = fminf(A.qub_arr[qid], (float)(bd[(k - 1) * PC_WAVE + lane] * (1.0 + 1e-6)));
-        return;  // stays flagged
+        const float ubf = (n >= k && !overflow) ? (float)(bd[(k - 1) * PC_WAVE + lane] * (1.0 + 1e-6)) : INFINITY;
+        A.qub_arr[qid] = A.qflag_in ? fminf(A.qub_arr[qid], ubf) : ubf;
+        A.qflag_out[qid] = 1;
+        return;  // flagged for the next level
     }
     A.qflag_out[qid] = 0;
     cnt = min(cnt, k);

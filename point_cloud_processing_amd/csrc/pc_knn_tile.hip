@@ -313,7 +313,10 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         // A coarser level whose open queries are spread thinly over its tiles (fewer than three per tile;
         // external queries always) is answered from the list of open queries, 64 to a wave, instead of a
         // workgroup per tile (measured: a gain for the short lists of k <= 16, a loss for k >= 20).
-        const bool batch = i > 0 && batch_passes && ks <= 18 && (A.qrec || open_prev < 3 * std::max<int64_t>(nt, 1));
+        // (the first pass of a thin uneven cloud, fewer than three points per occupied tile, likewise)
+        const bool batch = batch_passes && ks <= 18 && qflag != nullptr &&
+                           (i > 0 ? (A.qrec || open_prev < 3 * std::max<int64_t>(nt, 1))
+                                  : (!A.qrec && l->uneven && A.nq < 3 * std::max<int64_t>(nt, 1)));
         if (A.qrec && l->tile_list && !batch) {
             // the grid's list names the tiles that hold POINTS; external queries need the tiles that hold
             // queries (the block returns to the pool right away: everything using it is ordered on st)
@@ -326,10 +329,11 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
         if (batch) {
-            int64_t nopen = 0;
-            PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, open_list, &nopen, st));
+            int64_t nopen = A.nq;
+            if (i > 0)
+                PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, open_list, &nopen, st));
             if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass %d: %lld open queries\n", i, (long long)nopen);
-            PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
+            PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, i > 0 ? open_list : nullptr, nopen, st));
         } else {
             if (nt <= 0) continue;
             const int nw = std::max(1, l->tile_waves);
