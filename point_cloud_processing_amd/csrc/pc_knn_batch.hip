@@ -3,20 +3,23 @@
 // nearly empty waves.  The open queries, in the level's cell order, are dealt 64 to a wave; lane =
 // query.  Nothing is staged: a lane reads the records of its own 3x3x3 cells from global memory (L2
 // serves the neighbours' re-reads), in lock-step with its wave over the nine (y, z) row segments.
-//   pass A: the k-th smallest fp32-rounded exact distance.  Every squared distance is computed in
-//           fp64 in the reference's operation order; rounding it to fp32 is monotone, so a sorted
-//           register list of those u32 keys (one v_med3_u32 per slot and candidate) yields a
-//           threshold that no true neighbour exceeds.
-//   pass B: the same candidates again; those at or below the threshold (k of them, plus rounding
-//           ties) go with their fp64 distance into a lane-private LDS column, are ordered by
-//           (d2, original index) and certified against the distance to the unscanned cells exactly
-//           like in the tile kernel.  Uncertified queries keep their flag for the next level.
+// Every squared distance is computed in fp64 in the reference's operation order; its fp32 rounding
+// (monotone) with the low bits replaced by the candidate's ordinal is a unique u32 key.  A sorted
+// register list of KS = k + 2 keys (one v_med3_u32 per slot) takes only keys below its last entry,
+// which are parked in a lane-private LDS column and inserted in batches -- the tile kernel's
+// selection, fed from global memory.  The KS survivors are re-measured, ordered by (d2, original
+// index) and certified against the distance to the unscanned cells and to the unlisted candidates
+// exactly like in the tile kernel.  Uncertified queries get (or keep) their flag for the next level.
+#include <algorithm>
+
 #include "pc_knn_dev.h"
 
 namespace {
 
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
-constexpr int COL_EXTRA = 6;  // room for rounding ties beyond the list length
+constexpr int ORD_BITS = 11;   // a lane's candidates are numbered below 2^11 (crowded queries are left out)
+constexpr uint32_t ORD_MASK = (1u << ORD_BITS) - 1;
+constexpr int PARK_SLOTS = 14; // parked keys per lane between two sorted insertions
 
 template <int KS>
 __device__ inline void key_insert(uint32_t (&L)[KS], uint32_t key) {
@@ -34,9 +37,10 @@ __device__ inline int wave_max(int v) {
 template <typename REC, int KS, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_t *__restrict__ list, uint32_t count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CB = KS + COL_EXTRA;
-    double *bd = reinterpret_cast<double *>(smem);              // [CB][64] exact squared distances
-    uint32_t *bp = reinterpret_cast<uint32_t *>(bd + CB * PC_WAVE);  // [CB][64] sorted positions
+    // lane-private columns: parked keys during the filter, then the ordered result (same memory)
+    uint32_t *park = reinterpret_cast<uint32_t *>(smem);             // [PARK_SLOTS + 2][64]
+    double *bd = reinterpret_cast<double *>(smem);                   // [KS][64] exact squared distances
+    uint32_t *bp = reinterpret_cast<uint32_t *>(bd + KS * PC_WAVE);  // [KS][64] sorted positions
     const int lane = threadIdx.x;
     const int k = A.k;
     const GridParams &gp = A.gp;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     uint32_t total = 0;
 #pragma unroll
     for (int seg = 0; seg < 9; seg++) total += jn[seg];
-    const bool crowded = total > (uint32_t)A.cand_cap;
+    const bool crowded = total > (uint32_t)min(A.cand_cap, (int)ORD_MASK);
     if (crowded) {
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) jn[seg] = 0;
@@ -95,65 +99,49 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         return d;
     };
 
-    // ---- pass A: threshold ---------------------------------------------------------------------------
+    // ---- filter: one pass, keys below the list's last entry parked and inserted in batches -------------------
+    // key = (exact fp64 distance rounded to fp32, low ORD bits cleared) | ordinal of the candidate among
+    // this lane's candidates: unique, and monotone in the distance up to the cleared bits
+    uint32_t base[9];
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int seg = 0; seg < 9; seg++) {
+            base[seg] = acc;
+            acc += jn[seg];
+        }
+    }
     uint32_t L[KS];
 #pragma unroll
     for (int s = 0; s < KS; s++) L[s] = KEY_NONE;
-#pragma unroll
-    for (int seg = 0; seg < 9; seg++) {
-#pragma nounroll
-        for (int t = 0; t < tmax[seg]; t++) {
-            uint32_t key = KEY_NONE;
-            if ((uint32_t)t < jn[seg]) {
-                int32_t pid;
-                key = __float_as_uint((float)dist2(jb[seg] + t, pid));
-            }
+    uint32_t thr = KEY_NONE;
+    int parked = 0;
+    auto drain = [&]() {
+        int s = 0;
+        do {
+            const uint32_t key = s < parked ? park[s * PC_WAVE + lane] : KEY_NONE;
             key_insert<KS>(L, key);
-        }
-    }
-    // everything at or below the k-th smallest rounded distance holds the k nearest (all candidates
-    // if the cells hold fewer than k)
-    const uint32_t thr = (total >= (uint32_t)k) ? L[k - 1] : 0x7F800000u;
-
-    // ---- pass B: collect, order, certify ----------------------------------------------------------------
-    int n = 0;
-    bool overflow = false;
+            s++;
+        } while (__any(s < parked));
+        thr = L[KS - 1];
+        parked = 0;
+    };
 #pragma unroll
     for (int seg = 0; seg < 9; seg++) {
 #pragma nounroll
         for (int t = 0; t < tmax[seg]; t++) {
             if ((uint32_t)t < jn[seg]) {
                 int32_t pid;
-                const uint32_t j = jb[seg] + t;
-                const double d = dist2(j, pid);
-                if (__float_as_uint((float)d) <= thr) {
-                    if (n < CB) {
-                        // insertion by (d2, original index); ties fetch the index of the stored entry
-                        int p = n;
-                        while (p > 0) {
-                            const double dp = bd[(p - 1) * PC_WAVE + lane];
-                            if (dp < d) break;
-                            const uint32_t pp = bp[(p - 1) * PC_WAVE + lane];
-                            if (dp == d) {
-                                double tx, ty, tz;
-                                int32_t tid;
-                                RecTraits<REC>::load(rec + pp, tx, ty, tz, tid);
-                                if (tid < pid) break;
-                            }
-                            bd[p * PC_WAVE + lane] = dp;
-                            bp[p * PC_WAVE + lane] = pp;
-                            p--;
-                        }
-                        bd[p * PC_WAVE + lane] = d;
-                        bp[p * PC_WAVE + lane] = j;
-                        n++;
-                    } else {
-                        overflow = true;  // more rounding ties than the column holds
-                    }
+                const uint32_t key = (__float_as_uint((float)dist2(jb[seg] + t, pid)) & ~ORD_MASK) | (base[seg] + t);
+                if (key < thr) {
+                    park[parked * PC_WAVE + lane] = key;
+                    parked++;
                 }
             }
+            if (__any(parked >= PARK_SLOTS)) drain();
         }
     }
+    drain();
     if (!active) return;
     if (crowded) {
         if (!A.qflag_in) {  // first pass: flags and bounds are not initialised yet
@@ -163,7 +151,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         return;
     }
 
-    // no unscanned point is closer than sqrt(bound)
+    // ---- exact finish on the KS survivors -----------------------------------------------------------------
+    // no unscanned point is closer than sqrt(bound) ...
     bool whole = true;
     double dmin = INFINITY;
 #pragma unroll
@@ -183,21 +172,91 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         const double b = dmin - 1e-7 * gp.cell;
         bound = b > 0 ? b * b : 0.0;
     }
+    // ... and no unlisted candidate of the scanned cells is closer than sqrt(T * (1 - 2^-20))
+    if (L[KS - 1] != KEY_NONE) bound = fmin(bound, (double)__uint_as_float(L[KS - 1] & ~ORD_MASK) * (1.0 - 9.5367431640625e-07));
     const double r2lim = A.radius2;
-    int nsafe = 0, cnt = 0;
-    for (int s = 0; s < n; s++) {
-        const double d = bd[s * PC_WAVE + lane];
-        if (d < bound) {
-            nsafe++;
-            if (!(r2lim >= 0.0 && !(d < r2lim))) cnt++;  // (ascending: the accepted ones are a prefix)
+    double dd[KS];
+    uint32_t jj[KS];
+    int nsafe = 0, cnt = 0, nvalid = 0;
+    double dmax = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        dd[s] = INFINITY;
+        jj[s] = 0;
+        if (L[s] != KEY_NONE) {
+            const uint32_t o = L[s] & ORD_MASK;
+            uint32_t j = 0;
+#pragma unroll
+            for (int seg = 0; seg < 9; seg++)
+                if (o >= base[seg]) j = jb[seg] + (o - base[seg]);
+            int32_t pid;
+            const double d = dist2(j, pid);
+            jj[s] = j;
+            nvalid++;
+            dmax = fmax(dmax, d);
+            if (d < bound) {
+                nsafe++;
+                if (!(r2lim >= 0.0 && !(d < r2lim))) {
+                    dd[s] = d;
+                    cnt++;
+                }
+            }
         }
     }
-    const bool ok = !overflow && (nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim));
+    const bool ok = nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim);
     if (!ok) {
-        const float ubf = (n >= k && !overflow) ? (float)(bd[(k - 1) * PC_WAVE + lane] * (1.0 + 1e-6)) : INFINITY;
+        const float ubf = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
         A.qub_arr[qid] = A.qflag_in ? fminf(A.qub_arr[qid], ubf) : ubf;
         A.qflag_out[qid] = 1;
         return;  // flagged for the next level
+    }
+    // exact order: distance (bubble passes of min/max exchanges; the list is nearly sorted), then the rare
+    // equal distances by original index
+    auto orig_index = [&](uint32_t j) {
+        double x, y, z;
+        int32_t id;
+        RecTraits<REC>::load(rec + j, x, y, z, id);
+        return id;
+    };
+#pragma nounroll
+    for (int pass = 0; pass < KS; pass++) {
+        bool swapped = false;
+#pragma unroll
+        for (int s = 0; s + 1 < KS; s++) {
+            const double da = dd[s], db = dd[s + 1];
+            const uint32_t ja = jj[s], jb2 = jj[s + 1];
+            const bool gt = da > db;
+            dd[s] = fmin(da, db);
+            dd[s + 1] = fmax(da, db);
+            jj[s] = gt ? jb2 : ja;
+            jj[s + 1] = gt ? ja : jb2;
+            swapped |= gt;
+        }
+        if (!__any(swapped)) break;
+    }
+    bool ties = false;
+#pragma unroll
+    for (int s = 0; s + 1 < KS; s++) ties |= dd[s] == dd[s + 1] && dd[s] != INFINITY;
+    if (__any(ties)) {
+#pragma nounroll
+        for (int pass = 0; pass < KS; pass++) {
+            bool swapped = false;
+#pragma unroll
+            for (int s = 0; s + 1 < KS; s++) {
+                const uint32_t ja = jj[s], jb2 = jj[s + 1];
+                bool gt = false;
+                if (dd[s] == dd[s + 1] && dd[s] != INFINITY) gt = orig_index(ja) > orig_index(jb2);
+                jj[s] = gt ? jb2 : ja;
+                jj[s + 1] = gt ? ja : jb2;
+                swapped |= gt;
+            }
+            if (!__any(swapped)) break;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        bd[s * PC_WAVE + lane] = dd[s];
+        bp[s * PC_WAVE + lane] = jj[s];
     }
     A.qflag_out[qid] = 0;
     cnt = min(cnt, k);
@@ -221,7 +280,7 @@ void launch_mode(int mode, unsigned nb, size_t lds, hipStream_t st, const ScanAr
 
 template <typename REC>
 void launch_ks(int ks, int mode, unsigned nb, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count) {
-    const size_t lds = (sizeof(double) + sizeof(uint32_t)) * PC_WAVE * (size_t)(ks + COL_EXTRA);
+    const size_t lds = std::max((sizeof(double) + sizeof(uint32_t)) * PC_WAVE * (size_t)ks, sizeof(uint32_t) * PC_WAVE * (size_t)(PARK_SLOTS + 2));
     switch (ks) {
         case 4: launch_mode<REC, 4>(mode, nb, lds, st, A, list, count); break;
         case 10: launch_mode<REC, 10>(mode, nb, lds, st, A, list, count); break;
