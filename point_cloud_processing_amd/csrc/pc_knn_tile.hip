@@ -285,6 +285,11 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // coarser levels: a tile pass per occupied tile, or the open queries dealt 64 to a wave
     const bool batch_passes = getenv("PC_AMD_NO_BATCH") == nullptr;
     int64_t open_prev = 0;  // queries still open after the previous pass
+    const int64_t batch_min = 65536;
+    int list_level = -1, binned_level = 0;  // the level open_list / qrec_l were made for
+    int64_t list_count = 0;
+    const int batch_max_ks = getenv("PC_AMD_BATCH_KS") ? atoi(getenv("PC_AMD_BATCH_KS")) : 34;
+    const int64_t batch_ratio = getenv("PC_AMD_BATCH_RATIO") ? atoi(getenv("PC_AMD_BATCH_RATIO")) : 12;
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
     // external queries arrive binned into level 0; a coarser level bins them again into its own cells
     const void *qrec0 = A.qrec;
@@ -295,7 +300,8 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     for (int i = 0; i < nlv; i++) {
         const pc_grid *l = lv[i];
         if (A.qrec && i > 0) {
-            PC_TRY(pc_bin_queries(ctx, l, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+            if (binned_level != i) PC_TRY(pc_bin_queries(ctx, l, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+            binned_level = i;
             A.qrec = qrec_l.p;
             A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq, nullptr, 0u};
         }
@@ -310,13 +316,14 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         }
         A.tile_list = l->tile_list;
         if (l->tile_list) nt = l->tile_count;
-        // A coarser level whose open queries are spread thinly over its tiles (fewer than three per tile;
-        // external queries always) is answered from the list of open queries, 64 to a wave, instead of a
-        // workgroup per tile (measured: a gain for the short lists of k <= 16, a loss for k >= 20).
-        // (the first pass of a thin uneven cloud, fewer than three points per occupied tile, likewise)
-        const bool batch = batch_passes && ks <= 18 && qflag != nullptr &&
-                           (i > 0 ? (A.qrec || open_prev < 3 * std::max<int64_t>(nt, 1))
-                                  : (!A.qrec && l->uneven && A.nq < 3 * std::max<int64_t>(nt, 1)));
+        // A level whose (open) queries are spread thinly over its tiles -- fewer than a dozen per occupied
+        // tile; external queries on coarser levels always -- is answered from the list of open queries,
+        // 64 to a wave, instead of a workgroup per tile (measured on surfaces, clusters and planes + clutter:
+        // thresholds from 8 to "always" within 10 % of each other, 3 clearly slower).  Below 64 Ki queries the
+        // list would not fill the GPU's wave slots and the tile pass, one workgroup per tile, wins.
+        const bool batch = batch_passes && ks <= batch_max_ks && qflag != nullptr &&
+                           (i > 0 ? (A.qrec || (open_prev >= batch_min && open_prev < batch_ratio * std::max<int64_t>(nt, 1)))
+                                  : (!A.qrec && l->uneven && A.nq >= batch_min && A.nq < batch_ratio * std::max<int64_t>(nt, 1)));
         if (A.qrec && l->tile_list && !batch) {
             // the grid's list names the tiles that hold POINTS; external queries need the tiles that hold
             // queries (the block returns to the pool right away: everything using it is ordered on st)
@@ -330,7 +337,9 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
         if (batch) {
             int64_t nopen = A.nq;
-            if (i > 0)
+            if (i > 0 && list_level == i)
+                nopen = list_count;  // made when the previous pass was counted
+            else if (i > 0)
                 PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, open_list, &nopen, st));
             if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass %d: %lld open queries\n", i, (long long)nopen);
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, i > 0 ? open_list : nullptr, nopen, st));
@@ -358,8 +367,21 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         }
         if (qflag) {
             // how many points are still open decides whether another (coarser) pass is worth it
+            // (counted by listing the open queries in the NEXT level's order where that level may want the
+            // list: one read-back per level either way)
             int64_t open = 0;
-            PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
+            if (batch_passes && ks <= batch_max_ks && i + 1 < nlv) {
+                const pc_grid *nl = lv[i + 1];
+                if (qrec0) {
+                    PC_TRY(pc_bin_queries(ctx, nl, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+                    binned_level = i + 1;
+                }
+                PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : nl->rec, qrec0 ? A.nq : nl->n, qflag, open_list, &open, st));
+                list_level = i + 1;
+                list_count = open;
+            } else {
+                PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
+            }
             if (getenv("PC_AMD_DEBUG"))
                 fprintf(stderr, "[pc_amd]   level %d: cell %.4g dims %dx%dx%d tile %dx%dx%d cap %d tiles %lld sparse %d -> open %lld\n",
                         i, l->gp.cell, l->gp.dim[0], l->gp.dim[1], l->gp.dim[2], l->tile[0], l->tile[1], l->tile[2],
