@@ -112,11 +112,17 @@ struct pc_grid {
     // the same cloud on a 2x coarser grid (and that one's own `coarse`): built for clouds that
     // fill their box unevenly, used by the exact re-run of queries whose surroundings are sparse
     pc_grid *coarse = nullptr;
+    // ... and on a 2x finer grid (and that one's own `finer`): made on first need, for the points
+    // whose surroundings are too crowded for every level above; NULL until then
+    mutable pc_grid *finer = nullptr;
+    mutable bool finer_tried = false;  // a finer grid was asked for and cannot exist (cell-key range)
     int level = 0;        // 0: finest
     bool uneven = false;  // part of a multi-level index (set on every level)
 };
 
 // pc_grid.hip
+// the same cloud on cells of half the edge (cached in g->finer); *out = NULL if the key range forbids it
+int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out);
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
                    hipStream_t st);
 

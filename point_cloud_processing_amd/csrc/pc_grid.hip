@@ -337,6 +337,17 @@ __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ 
     }
 }
 
+// the inverse of k_gather_records: coordinates back at their original index
+template <typename T, typename REC>
+__global__ __launch_bounds__(256) void k_scatter_coords(const REC *__restrict__ rec, int64_t n, T *__restrict__ xyz) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const REC r = rec[i];
+    xyz[3 * (size_t)r.idx] = r.x;
+    xyz[3 * (size_t)r.idx + 1] = r.y;
+    xyz[3 * (size_t)r.idx + 2] = r.z;
+}
+
 template <typename T, typename REC>
 __global__ __launch_bounds__(256) void k_gather_records(const T *__restrict__ xyz, const uint32_t *__restrict__ vals,
                                                          int64_t n, REC *__restrict__ rec,
@@ -780,8 +791,11 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
     // Unevenly filled box (surfaces, clusters, clutter): add coarser levels, twice the edge
     // each, so that a query in a sparse region finds k neighbours within one ring of SOME level.
     // (a cloud that fills its box evenly leaves exp(-mean occupancy) of the cells empty by chance)
-    const double chance_filled = 1.0 - exp(-(double)n / (double)std::max<int64_t>(1, g->ncell));
-    if (automatic && n > 4096 && g->occupied > 0 && (double)g->occupied < 0.85 * chance_filled * (double)g->ncell) {
+    // (and a grid with more cells than points is mostly empty box whatever the count says)
+    const double mean_occ = (double)n / (double)std::max<int64_t>(1, g->ncell);
+    const double chance_filled = 1.0 - exp(-mean_occ);
+    if (automatic && n > 4096 && g->occupied > 0 &&
+        (mean_occ < 1.0 || (double)g->occupied < 0.85 * chance_filled * (double)g->ncell)) {
         pc_grid *fine = g;
         g->uneven = true;
         for (int lv = 1; lv < MAX_LEVELS; lv++) {
@@ -804,6 +818,34 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
 }
 
 }  // extern "C"
+
+int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out) {
+    *out = g->finer;
+    if (g->finer || g->finer_tried || g->n <= 0) return PC_OK;
+    g->finer_tried = true;
+    // the builder wants the cloud as an array: put the records' coordinates back at their indices
+    const size_t esz = g->dtype == PC_F32 ? sizeof(float) : sizeof(double);
+    Scratch xyz(ctx, 3 * esz * (size_t)g->n);
+    if (!xyz.ok()) return pc_fail(ctx, PC_NOMEM, "finer grid");
+    if (g->dtype == PC_F32)
+        hipLaunchKernelGGL((k_scatter_coords<float, Rec32>), dim3(blocks_for(g->n, 256)), dim3(256), 0, st,
+                           (const Rec32 *)g->rec, g->n, xyz.as<float>());
+    else
+        hipLaunchKernelGGL((k_scatter_coords<double, Rec64>), dim3(blocks_for(g->n, 256)), dim3(256), 0, st,
+                           (const Rec64 *)g->rec, g->n, xyz.as<double>());
+    PC_HIP(hipGetLastError());
+    pc_grid *f = nullptr;
+    PC_TRY(pc_grid_build(ctx, xyz.p, g->dtype, g->n, 0.5 * g->gp.cell, 0, &f, (void *)st));
+    if (f->gp.cell > 0.93 * g->gp.cell) {  // the cell-key range binds: no finer grid
+        pc_grid_destroy(ctx, f);
+        return PC_OK;
+    }
+    f->uneven = true;
+    f->level = g->level - 1;
+    g->finer = f;
+    *out = f;
+    return PC_OK;
+}
 
 // External queries binned into a grid: records {x, y, z, query row} in the order of the grid's cell
 // keys (ties by query row) and the sorted keys themselves.  The queries have the grid's dtype.
@@ -840,6 +882,7 @@ extern "C" {
 void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
     if (!g) return;
     if (g->coarse) pc_grid_destroy(ctx, g->coarse);
+    if (g->finer) pc_grid_destroy(ctx, g->finer);
     if (ctx) {
         if (g->rec) ctx->release(g->rec);
         if (g->cell_start) ctx->release(g->cell_start);

@@ -392,6 +392,48 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             if (open < std::max<int64_t>(2048, A.nq / 200)) break;
         }
     }
+    // Points still open after the ladder are either isolated (nothing helps but the wave-per-query
+    // kernel) or sit amid more candidates than any level above could stage: for those, up to three grids
+    // of half the cell edge each, made on first need and kept with the index.  A pass costs little for
+    // the isolated ones (their cells are nearly empty); going finer stops when it closes under 5 %.
+    uint32_t crowded = 0;
+    if (qflag && batch_passes && !getenv("PC_AMD_NO_FINER") && open_prev >= std::max<int64_t>(2048, A.nq / 200)) {
+        uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pinned);
+        PC_HIP(hipMemcpyAsync(h, A.flag_count + 26, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PC_HIP(hipStreamSynchronize(st));
+        crowded = h[0];  // queries the FIRST pass found amid more candidates than a tile stages
+        if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   %lld open after the ladder, %u crowded in the first pass\n", (long long)open_prev, crowded);
+    }
+    if (crowded >= std::max<int64_t>(2048, A.nq / 100)) {
+        const pc_grid *fine = g;
+        for (int f = 0; f < 3; f++) {
+            const pc_grid *nf = nullptr;
+            PC_TRY(pc_grid_finer(ctx, fine, st, &nf));
+            if (!nf) break;
+            fine = nf;
+            if (qrec0) {
+                PC_TRY(pc_bin_queries(ctx, fine, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+                A.qrec = qrec_l.p;
+                A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq, nullptr, 0u};
+            }
+            A.gp = fine->gp;
+            A.rec = fine->rec;
+            A.ci = fine->index();
+            A.cand_cap = UNEVEN_CAP;
+            A.qflag_in = qflag;
+            A.qflag_out = qflag;
+            int64_t nopen = 0, open = 0;
+            PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : fine->rec, qrec0 ? A.nq : fine->n, qflag, open_list, &nopen, st));
+            PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
+            PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
+            if (getenv("PC_AMD_DEBUG"))
+                fprintf(stderr, "[pc_amd]   finer level: cell %.4g, %lld open queries -> %lld\n", fine->gp.cell, (long long)nopen,
+                        (long long)open);
+            const bool progress = nopen - open >= nopen / 20;
+            open_prev = open;
+            if (!progress || open < std::max<int64_t>(2048, A.nq / 200)) break;
+        }
+    }
     if (qflag) {
         // back to level 0: the re-run lists hold level-0 sorted positions
         A.gp = g->gp;

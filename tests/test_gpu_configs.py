@@ -90,3 +90,20 @@ def test_level_passes_agree(hip, oracle, monkeypatch, k):
     assert np.array_equal(a_ext[0], ridx) and np.array_equal(a_ext[1], rd2) and np.array_equal(a_ext[2], rcnt)
     ridx, rd2, rcnt = oracle.Grid(p).knn_self(k)
     assert np.array_equal(a_self[0], ridx) and np.array_equal(a_self[1], rd2)
+
+
+def test_crowded_patch_gets_finer_levels(hip, oracle):
+    """A small patch far denser than the rest (more candidates around its points than a tile stages, at
+    every level of the index): answered through the finer grids made on demand and the wave-per-query
+    kernel; the same index answers a second search identically."""
+    rng = np.random.default_rng(31)
+    a = np.c_[rng.random((12_000, 2)) * 0.3 + 30.0, 10.0 + rng.normal(0, 0.002, 12_000)]
+    b = np.c_[rng.random((260_000, 2)) * 60.0, 20.0 + rng.normal(0, 0.002, 260_000)]
+    c = rng.random((128_000, 3)) * 60.0
+    p = np.concatenate([a, b, c]).astype(np.float32).astype(np.float64)
+    cache = {}
+    idx, d2, cnt = hip.knn(p, None, 12, -1.0, cache)
+    ridx, rd2, rcnt = oracle.Grid(p).knn_self(12)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+    again = hip.knn(p, None, 12, -1.0, cache)
+    assert np.array_equal(again[0], idx) and np.array_equal(again[1], d2)
