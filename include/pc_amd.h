@@ -148,6 +148,14 @@ int pc_nn_distance(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_
 int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
                    void *stream);
 
+/* PointCloud.orient_normals_consistent_tangent_plane(k) (app/Core/pointcloud_preprocess.py:115): turns the
+ * n normals (n x 3 fp64, in place) so that they agree along the minimum spanning tree of the neighbour graph
+ * given by knn_idx (n x k rows of pc_knn over the same cloud; knn_cnt = valid entries per row, or NULL: all),
+ * edge weight 1 - |n_i . n_j|; every connected piece is turned so that its highest point (xyz, n x 3 of
+ * dtype) looks towards +z.  *out_pieces = number of connected pieces.  Needs n * k < 2^32. */
+int pc_orient_normals(pc_ctx *ctx, const void *xyz_dev, int dtype, double *normals_dev, const int32_t *knn_idx_dev,
+                      const int32_t *knn_cnt_dev, int64_t n, int k, int64_t *out_pieces, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ class OracleEngine:
     def nn_distance(self, pts, cache):
         return O.nn_distance(pts)
 
+    def orient_normals(self, pts, nrm, k, cache):
+        idx, _, cnt = O.knn(pts, None, k, None)
+        return O.orient_normals(pts, nrm, idx, cnt)
+
     def knn(self, pts, q, k, radius, cache):
         return O.knn(pts, q, k, None if radius < 0 else radius)
 

@@ -213,3 +213,64 @@ def fast_eigen3x3(cov6):
     out = np.zeros(3)
     lib().orc_fast_eigen3x3(_p(c), _p(out))
     return out
+
+
+def orient_normals(pts, nrm, idx, cnt=None):
+    """Normal signs propagated along the minimum spanning tree of the neighbour graph: the host-side
+    statement of what PointCloud.orient_normals_consistent_tangent_plane does at
+    app/Core/pointcloud_preprocess.py:115 (Hoppe et al. 1992; Open3D adds Delaunay edges to join
+    disconnected pieces, here every piece is oriented on its own).
+
+    Graph: one undirected edge per neighbour slot (i, s) -> idx[i, s]; weight 1 - |n_i . n_j| rounded to
+    fp32; edges are totally ordered by (weight bits, slot number), which makes the tree unique.  Seed of
+    a piece: its highest point (lowest index among equals), turned towards +z; a normal is reversed when
+    it opposes its tree parent.  Returns (normals, number of connected pieces)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import breadth_first_order, connected_components, minimum_spanning_tree
+
+    pts = np.asarray(pts, dtype=np.float64)
+    nrm = np.array(nrm, dtype=np.float64, copy=True)
+    n, k = idx.shape
+    if n == 0:
+        return nrm, 0
+    rows = np.repeat(np.arange(n, dtype=np.int64), k)
+    cols = idx.reshape(-1).astype(np.int64)
+    ok = (cols >= 0) & (cols < n) & (cols != rows)
+    if cnt is not None:
+        ok &= (np.arange(k)[None, :] < np.asarray(cnt)[:, None]).reshape(-1)
+    slot = np.nonzero(ok)[0]
+    rows, cols = rows[ok], cols[ok]
+    a, b = nrm[rows], nrm[cols]
+    dot = (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]
+    w = (1.0 - np.abs(dot)).astype(np.float32)
+    w[~(w > 0)] = 0.0
+    key = (w.view(np.uint32).astype(np.uint64) << np.uint64(32)) | slot.astype(np.uint64)
+    rank = np.empty(len(key), dtype=np.float64)
+    rank[np.argsort(key, kind="stable")] = np.arange(1, len(key) + 1, dtype=np.float64)
+    # (i, j) and (j, i) may both be listed: the spanning tree routine takes the smaller of the two
+    g = csr_matrix((rank, (rows, cols)), shape=(n, n))
+    ncomp, label = connected_components(g, directed=False)
+    mst = minimum_spanning_tree(g)
+    mst = mst + mst.T
+    z = pts[:, 2] + 0.0
+    order = np.lexsort((np.arange(n), -z, label))  # per piece: highest point first, lowest index among equals
+    first = np.ones(n, dtype=bool)
+    first[1:] = label[order][1:] != label[order][:-1]
+    parent = np.arange(n, dtype=np.int64)
+    for s in order[first]:
+        _, pred = breadth_first_order(mst, int(s), directed=False, return_predecessors=True)
+        m = pred >= 0
+        parent[m] = pred[m]
+    # sign of a point = sign of its seed x product of the edge signs on its tree path (pointer doubling)
+    pn = nrm[parent]
+    pdot = (nrm[:, 0] * pn[:, 0] + nrm[:, 1] * pn[:, 1]) + nrm[:, 2] * pn[:, 2]
+    acc = np.where(pdot < 0.0, -1.0, 1.0)
+    acc[parent == np.arange(n)] = 1.0
+    par = parent.copy()
+    for _ in range(int(np.ceil(np.log2(max(n, 2)))) + 1):
+        acc = acc * acc[par]
+        par = par[par]
+    seed_sign = np.where(nrm[:, 2] < 0.0, -1.0, 1.0)
+    sign = acc * seed_sign[par]
+    nrm[sign < 0] *= -1.0
+    return nrm, int(ncomp)

@@ -44,6 +44,7 @@ SYMBOLS = [
     ("pc_radius_count", _i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _dbl, _vp, _vp]),
     ("pc_nn_distance", _i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     ("pc_gather_rows", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    ("pc_orient_normals", _i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
 ]
 
 _lib = None

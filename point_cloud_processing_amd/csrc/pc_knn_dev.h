@@ -361,7 +361,7 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
     }
 }
 
-// pc_knn_tile.hip: the tile-cooperative fast path (self-queries, k <= 32).
+// pc_knn_tile.hip: the tile-cooperative fast path (self-queries, k <= 50).
 // Returns PC_OK after enqueueing; *handled = false when the configuration is not supported.
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled);
 // pc_knn_tile_*.hip: the tile kernel for one record type, with / without sub-tile splitting

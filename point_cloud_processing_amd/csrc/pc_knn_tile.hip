@@ -1,4 +1,4 @@
-// Tile-cooperative exact kNN (k <= 32; fp32 and fp64 grids; the grid's own points or external
+// Tile-cooperative exact kNN (k <= 50; fp32 and fp64 grids; the grid's own points or external
 // queries binned into the grid).  This file: the host side (tile shapes, occupied-tile lists, the
 // passes over the index levels); the kernel lives in pc_knn_tile_kernel.h.
 //
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__
 
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled) {
     *handled = false;
-    if (A.queries != nullptr || A.k > 32 || mode == M_COUNT || A.nq <= 0) return PC_OK;
+    if (A.queries != nullptr || A.k > 50 || mode == M_COUNT || A.nq <= 0) return PC_OK;
     if (getenv("PC_AMD_EXACT_SCAN_ONLY")) return PC_OK;  // A/B switch: one-query-per-lane fp64 scan only
     // the levels of the index, finest first; every level gets a tile pass, a coarser one answering
     // only what the finer ones flagged
@@ -290,7 +290,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     int64_t list_count = 0;
     const int batch_max_ks = getenv("PC_AMD_BATCH_KS") ? atoi(getenv("PC_AMD_BATCH_KS")) : 34;
     const int64_t batch_ratio = getenv("PC_AMD_BATCH_RATIO") ? atoi(getenv("PC_AMD_BATCH_RATIO")) : 12;
-    const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : 34)));
+    const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : (A.k <= 32 ? 34 : 52))));
     // external queries arrive binned into level 0; a coarser level bins them again into its own cells
     const void *qrec0 = A.qrec;
     const CellIndex qci0 = A.qci;

@@ -670,7 +670,8 @@ void launch_tile_ks(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipS
         case 10: launch_tile<REC, 10, SPLIT>(mode, nblocks, nw, lds, st, A); break;
         case 18: launch_tile<REC, 18, SPLIT>(mode, nblocks, nw, lds, st, A); break;
         case 22: launch_tile<REC, 22, SPLIT>(mode, nblocks, nw, lds, st, A); break;
-        default: launch_tile<REC, 34, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        case 34: launch_tile<REC, 34, SPLIT>(mode, nblocks, nw, lds, st, A); break;
+        default: launch_tile<REC, 52, SPLIT>(mode, nblocks, nw, lds, st, A); break;
     }
 }
 

@@ -245,56 +245,16 @@ class PointCloud:
     def orient_normals_consistent_tangent_plane(self, k: int) -> None:
         """Consistent normal signs by propagation along a minimum spanning tree (Hoppe et al. 1992, the
         scheme behind PointCloud.orient_normals_consistent_tangent_plane, pointcloud_preprocess.py:115):
-        graph = the symmetric k-nearest-neighbour graph (neighbour search on the engine), edge weight
-        1 - |n_i . n_j|, seed = the highest point of each connected piece with its normal turned to +z,
-        a normal is flipped when it opposes its tree parent.  The tree itself is a host-side
-        scipy.sparse.csgraph computation (sequential by nature); without scipy the signs stay as
-        computed.  Open3D joins disconnected pieces through a Delaunay-based spanning tree; here each
-        piece is oriented on its own, so signs agree with Open3D's within a piece up to a global flip."""
+        graph = the k-nearest-neighbour graph taken as undirected, edge weight 1 - |n_i . n_j|, seed = the
+        highest point of each connected piece with its normal turned to +z, a normal is flipped when it
+        opposes its tree parent.  Search, spanning tree and sign propagation all run on the engine.
+        Open3D joins disconnected pieces through a Delaunay-based spanning tree; here each piece is
+        oriented on its own, so signs agree with Open3D's within a piece up to a global flip."""
         n = len(self)
         if self._normals is None or n == 0:
             raise RuntimeError("[Open3D Error] No normals in the PointCloud. Call EstimateNormals() first.")
-        try:
-            from scipy.sparse import csr_matrix
-            from scipy.sparse.csgraph import breadth_first_order, connected_components, minimum_spanning_tree
-        except ImportError:  # pragma: no cover
-            print("[Preprocess] scipy is not available: normal signs left as computed")
-            return
-        kk = max(2, min(int(k), n))
-        idx, _, cnt = _engine.get().knn(self._points, None, kk, -1.0, self._cache)
-        nrm = self._normals
-        rows = np.repeat(np.arange(n, dtype=np.int64), kk)
-        cols = idx.reshape(-1).astype(np.int64)
-        ok = (np.arange(kk)[None, :] < cnt[:, None]).reshape(-1) & (cols != rows) & (cols >= 0)
-        rows, cols = rows[ok], cols[ok]
-        # (explicit zeros vanish from a sparse matrix: keep every edge strictly positive)
-        w = 1.0 - np.abs(np.einsum("ij,ij->i", nrm[rows], nrm[cols])) + 1e-9
-        g = csr_matrix((w, (rows, cols)), shape=(n, n))
-        g = g.maximum(g.T)
-        ncomp, label = connected_components(g, directed=False)
-        mst = minimum_spanning_tree(g)
-        mst = mst + mst.T
-        z = self._points[:, 2]
-        order = np.lexsort((-z, label))  # per piece: highest point first
-        first = np.ones(n, dtype=bool)
-        first[1:] = label[order][1:] != label[order][:-1]
-        seeds = order[first]
-        parent = np.arange(n, dtype=np.int64)
-        for s in seeds:
-            _, pred = breadth_first_order(mst, int(s), directed=False, return_predecessors=True)
-            m = pred >= 0
-            parent[m] = pred[m]
-        # sign of a point = sign of its seed x product of the edge signs on its tree path, by pointer
-        # doubling: after t rounds `acc` covers the first 2^t edges of the path, `par` points 2^t up
-        me = np.arange(n)
-        acc = np.where(np.einsum("ij,ij->i", nrm, nrm[parent]) < 0.0, -1.0, 1.0)  # flip relative to the parent
-        acc[parent == me] = 1.0
-        par = parent.copy()
-        for _ in range(int(np.ceil(np.log2(max(n, 2)))) + 1):
-            acc = acc * acc[par]
-            par = par[par]
-        seed_sign = np.where(nrm[:, 2] < 0.0, -1.0, 1.0)  # a seed looks towards +z
-        self._normals = nrm * (acc * seed_sign[par])[:, None]
+        kk = max(2, min(int(k), n, 64))
+        self._normals, _ = _engine.get().orient_normals(self._points, self._normals, kk, self._cache)
 
     def remove_statistical_outlier(self, nb_neighbors: int, std_ratio: float, print_progress: bool = False):
         if nb_neighbors < 1 or not (std_ratio > 0):

@@ -310,6 +310,22 @@ class HipEngine:
         out = cnt.cpu().numpy()
         return out if cap is None else np.minimum(out, int(cap))
 
+    def orient_normals(self, pts, nrm, k, cache):
+        """Normals turned to agree along the spanning tree of the k-neighbour graph; the neighbour rows
+        never leave the device.  Returns (normals, number of connected pieces)."""
+        n = len(pts)
+        g = self.grid(pts, cache, k)
+        t = self.dev_points(pts, cache)
+        idx = self.empty((n, k), torch.int32)
+        cnt = self.empty((n,), torch.int32)
+        self._check(self.lib.pc_knn(self.ctx, g.h, None, _lib.PC_F64, n, int(k), -1.0, _ptr(idx), None, _lib.PC_F32,
+                                    _ptr(cnt), self.stream()), "pc_knn")
+        dn = self.upload(np.asarray(nrm, dtype=np.float64))
+        pieces = C.c_int64(0)
+        self._check(self.lib.pc_orient_normals(self.ctx, _ptr(t), self._dt(t), _ptr(dn), _ptr(idx), _ptr(cnt), n, int(k),
+                                               C.byref(pieces), self.stream()), "pc_orient_normals")
+        return dn.cpu().numpy(), int(pieces.value)
+
     def nn_distance(self, pts, cache):
         g = self.grid(pts, cache, 2)
         n = len(pts)

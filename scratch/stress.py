@@ -33,7 +33,7 @@ for case in range(ncase):
         p = np.round(r.random((n, 3)) * 12.0) / 4.0
     p = p * float(rng.choice([1.0, 1e-3, 1e3])) + float(rng.choice([0.0, 100.0]))
     if fp32: p = p.astype(np.float32).astype(np.float64)
-    k = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 20, 25, 30, 32, 40]))
+    k = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 20, 25, 30, 32, 33, 40, 50, 51]))
     radius = -1.0 if rng.random() < 0.7 else float(np.ptp(p, axis=0).max() * rng.choice([0.002, 0.02, 0.2]))
     ext = rng.random() < 0.35
     q = None

@@ -56,3 +56,34 @@ def test_sor_cache_reused_across_relax_attempts(hip):
     avg = pcd._cache[("sor_avg", 30)]
     b, ib = pcd.remove_statistical_outlier(30, 3.8)
     assert pcd._cache[("sor_avg", 30)] is avg and len(ib) >= len(ia)
+
+
+@pytest.mark.parametrize("case", ["two_spheres", "torus_k50", "lattice_ties", "clusters"])
+def test_orient_normals_matches_oracle(hip, oracle, case):
+    """pc_orient_normals against the oracle's spanning-tree propagation: the edge order (fp32 weight bits,
+    then slot number) makes the tree unique, so every sign must agree; piece counts too."""
+    rng = np.random.default_rng(11)
+    k = 10
+    if case == "two_spheres":
+        p = rng.standard_normal((9000, 3))
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        p = np.concatenate([p[:6000], p[6000:] * 0.5 + np.array([10.0, 0.0, 0.0])])
+    elif case == "torus_k50":
+        p, k = D.torus(20000, 6), 50
+    elif case == "lattice_ties":  # a flat lattice: all weights equal, the slot number alone orders the edges
+        gx, gy = np.meshgrid(np.arange(40.0), np.arange(40.0))
+        p, k = np.stack([gx.ravel(), gy.ravel(), np.zeros(1600)], 1), 9
+    else:  # many pieces of very different sizes, some below k points
+        p = np.concatenate([D.gaussian_clusters(5000, 3), rng.random((7, 3)) + 50.0, rng.random((1, 3)) - 70.0])
+    p = np.ascontiguousarray(p.astype(np.float32).astype(np.float64))
+    k = min(k, len(p))
+    nrm = oracle.normals(p, 12)
+    nrm[rng.random(len(p)) < 0.5] *= -1.0
+    idx, _, cnt = oracle.knn(p, None, k, None)
+    want, pieces = oracle.orient_normals(p, nrm, idx, cnt)
+    got, got_pieces = hip.orient_normals(p, nrm, k, {})
+    assert got_pieces == pieces
+    assert np.array_equal(got, want)
+    if case == "two_spheres":
+        centre = np.where((np.arange(len(p)) < 6000)[:, None], 0.0, np.array([10.0, 0.0, 0.0]))
+        assert (np.einsum("ij,ij->i", got, p - centre) > 0).all()

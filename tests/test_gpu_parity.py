@@ -28,7 +28,7 @@ def angle_up_to_sign(a, b):
 
 
 @pytest.mark.parametrize("name", list(CLOUDS))
-@pytest.mark.parametrize("k", [1, 2, 16, 30])
+@pytest.mark.parametrize("k", [1, 2, 16, 30, 50])
 def test_knn_self(hip, oracle, name, k):
     p = CLOUDS[name]()
     idx, d2, cnt = hip.knn(p, None, k, -1.0, {})
