@@ -86,6 +86,19 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) jn[seg] = 0;
     }
+    // ... and one with fewer than 2 k candidates in its 27 cells will not find k of them inside the reach of
+    // those cells (a ball inscribed in the block holds a fifth of an evenly filled block's points, under
+    // half of a surface's): it waits for coarser cells without costing the wave any steps.  (Not when the
+    // 27 cells are the whole grid or a radius limits the search: few neighbours are the answer then.)
+    {
+        bool whole_grid = true;
+#pragma unroll
+        for (int a = 0; a < 3; a++) whole_grid = whole_grid && c[a] <= 1 && c[a] + 1 >= gp.dim[a] - 1;
+        if (total < 2u * (uint32_t)k && !whole_grid && A.radius2 < 0.0) {
+#pragma unroll
+            for (int seg = 0; seg < 9; seg++) jn[seg] = 0;
+        }
+    }
     if (!A.qflag_in) {  // first pass: how many queries are crowded decides whether finer grids are worth making
         const unsigned long long m = __ballot(crowded);
         if (lane == 0 && m) atomicAdd(A.flag_count + 26, (uint32_t)__popcll(m));

@@ -386,8 +386,10 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                 fprintf(stderr, "[pc_amd]   level %d: cell %.4g dims %dx%dx%d tile %dx%dx%d cap %d tiles %lld sparse %d -> open %lld\n",
                         i, l->gp.cell, l->gp.dim[0], l->gp.dim[1], l->gp.dim[2], l->tile[0], l->tile[1], l->tile[2],
                         l->tile_cap, (long long)nt, l->keys != nullptr, (long long)open);
-            // a pass that closed next to nothing: the open points wait for much coarser cells, skip one level
-            if (i > 0 && !getenv("PC_AMD_NO_LEVEL_SKIP") && open_prev - open < open_prev / 100 && i + 2 < nlv) i++;
+            // (No level is skipped after a pass that closed next to nothing: the next one may be the only
+            // level whose cells suit the open points -- coarser ones hold more candidates than a tile stages.
+            // Measured on 66 M voxels of planes + clutter: skipping sent 30 M queries to the wave-per-query
+            // kernel, 658 ms against 352 ms.)
             open_prev = open;
             if (open < std::max<int64_t>(2048, A.nq / 200)) break;
         }

@@ -355,6 +355,25 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             seg_pack[seg] = st | (ln << 16);
             seg_max[seg] = (int)ln;
         }
+        // A query with fewer than 2 k candidates in its 27 cells will not find k of them inside the reach of
+        // those cells (a ball inscribed in the block holds a fifth of an evenly filled block's points, under
+        // half of a surface's): it is handed on without costing the wave any steps.  (Not when the 27 cells
+        // are the whole grid or a radius limits the search: few neighbours are the answer then.)
+        {
+            uint32_t total = 0;
+            bool whole_grid = true;
+#pragma unroll
+            for (int seg = 0; seg < 9; seg++) total += seg_pack[seg] >> 16;
+#pragma unroll
+            for (int a = 0; a < 3; a++) whole_grid = whole_grid && qc[a] <= 1 && qc[a] + 1 >= gp.dim[a] - 1;
+            if (total < 2u * (uint32_t)k && !whole_grid && r2lim < 0.0) {
+#pragma unroll
+                for (int seg = 0; seg < 9; seg++) {
+                    seg_pack[seg] &= 0xffffu;
+                    seg_max[seg] = 0;
+                }
+            }
+        }
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) seg_max[seg] = wave_max_i32(seg_max[seg]);
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
