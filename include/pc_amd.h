@@ -156,6 +156,19 @@ int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, i
 int pc_orient_normals(pc_ctx *ctx, const void *xyz_dev, int dtype, double *normals_dev, const int32_t *knn_idx_dev,
                       const int32_t *knn_cnt_dev, int64_t n, int k, int64_t *out_pieces, void *stream);
 
+/* One linearised step of point-to-plane ICP.  The reference only advertises ICP (app/UI/main_window.py:58,
+ * 180-194 lead to a stub); the arithmetic is Open3D's TransformationEstimationPointToPlane: for every source
+ * point i with a correspondence j = corr_idx[i] >= 0 and corr_d2[i] < max_d2: r = (s_i - t_j) . n_j,
+ * J = [s_i x n_j, n_j].  out_terms (host) = the 21 upper-triangle entries of sum J J^T (row by row), the 6 of
+ * sum J r, sum of corr_d2 and the number of correspondences used.  src: m x 3 fp64 (already transformed);
+ * corr_idx / corr_d2: the rows of pc_knn(k = 1) for src against the target.  Synchronises the stream. */
+int pc_icp_point_to_plane_terms(pc_ctx *ctx, const double *src_dev, int64_t m, const void *tgt_xyz_dev, int tgt_dtype,
+                                const double *tgt_normals_dev, const int32_t *corr_idx_dev, const void *corr_d2_dev,
+                                int d2_dtype, double max_d2, double out_terms[29], void *stream);
+
+/* PointCloud.transform: p <- R p + t over n points (fp64, in place); T = 4 x 4 row-major, last row ignored. */
+int pc_transform(pc_ctx *ctx, double *xyz_dev, int64_t n, const double T[16], void *stream);
+
 #ifdef __cplusplus
 }
 #endif

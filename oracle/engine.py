@@ -10,8 +10,52 @@ import numpy as np
 from . import pc_oracle as O
 
 
+class OracleIcpSession:
+    """The ICP primitives in numpy (Open3D's TransformationEstimationPointToPlane arithmetic)."""
+
+    def __init__(self, src, tgt, tgt_normals):
+        self.src = np.array(src, dtype=np.float64, copy=True)
+        self.tgt = np.ascontiguousarray(tgt, dtype=np.float64)
+        self.tn = np.ascontiguousarray(tgt_normals, dtype=np.float64)
+        self.idx = self.d2 = None
+
+    def transform(self, t):
+        t = np.asarray(t, dtype=np.float64).reshape(4, 4)
+        x, y, z = self.src[:, 0].copy(), self.src[:, 1].copy(), self.src[:, 2].copy()
+        for a in range(3):
+            self.src[:, a] = ((t[a, 0] * x + t[a, 1] * y) + t[a, 2] * z) + t[a, 3]
+
+    def correspond(self):
+        idx, d2, _ = O.knn(self.tgt, np.ascontiguousarray(self.src), 1, None)
+        self.idx, self.d2 = idx[:, 0], d2[:, 0]
+
+    def _used(self, max_dist):
+        return np.nonzero((self.idx >= 0) & (self.d2 < float(max_dist) ** 2))[0]
+
+    def terms(self, max_dist):
+        rows = self._used(max_dist)
+        s, j = self.src[rows], self.idx[rows]
+        t, n = self.tgt[j], self.tn[j]
+        r = ((s[:, 0] - t[:, 0]) * n[:, 0] + (s[:, 1] - t[:, 1]) * n[:, 1]) + (s[:, 2] - t[:, 2]) * n[:, 2]
+        jac = np.concatenate([np.cross(s, n), n], axis=1)
+        jtj = jac.T @ jac
+        out = np.zeros(29)
+        out[:21] = jtj[np.triu_indices(6)]
+        out[21:27] = jac.T @ r
+        out[27] = self.d2[rows].sum()
+        out[28] = len(rows)
+        return out
+
+    def correspondence_set(self, max_dist):
+        rows = self._used(max_dist)
+        return np.stack([rows.astype(np.int32), self.idx[rows].astype(np.int32)], axis=1)
+
+
 class OracleEngine:
     name = "oracle"
+
+    def icp_session(self, src, tgt, tgt_normals):
+        return OracleIcpSession(src, tgt, tgt_normals)
 
     def bbox(self, pts, cache):
         return O.bbox(pts)

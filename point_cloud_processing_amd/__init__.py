@@ -14,6 +14,7 @@ from .geometry import (  # noqa: F401
     Vector3dVector,
 )
 from ._engine import get as get_engine, set_engine  # noqa: F401
+from .registration import RegistrationResult, registration_icp  # noqa: F401
 
 __all__ = [
     "PointCloud",
@@ -22,6 +23,8 @@ __all__ = [
     "KDTreeSearchParamKNN",
     "KDTreeSearchParamRadius",
     "KDTreeSearchParamHybrid",
+    "RegistrationResult",
+    "registration_icp",
     "get_engine",
     "set_engine",
 ]

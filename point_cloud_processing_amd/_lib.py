@@ -45,6 +45,8 @@ SYMBOLS = [
     ("pc_nn_distance", _i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     ("pc_gather_rows", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     ("pc_orient_normals", _i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    ("pc_icp_point_to_plane_terms", _i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
+    ("pc_transform", _i32, [_vp, _vp, _i64, _vp, _vp]),
 ]
 
 _lib = None

@@ -52,6 +52,43 @@ class DeviceGrid:
             pass
 
 
+class HipIcpSession:
+    """Device state of one ICP run: the moving source, the target with its index (fp64, so that the fp64
+    source takes the tile kernel as binned external queries) and the current correspondences."""
+
+    def __init__(self, eng: "HipEngine", src: np.ndarray, tgt: np.ndarray, tgt_normals: np.ndarray):
+        self.eng, self.m = eng, len(src)
+        self.src = eng.upload(np.asarray(src, dtype=np.float64))
+        self.tgt = eng.upload(np.asarray(tgt, dtype=np.float64))
+        self.tn = eng.upload(np.asarray(tgt_normals, dtype=np.float64))
+        self.grid = DeviceGrid(eng, self.tgt, len(tgt), 1)
+        self.idx = eng.empty((self.m, 1), torch.int32)
+        self.d2 = eng.empty((self.m, 1), torch.float64)
+
+    def transform(self, t: np.ndarray) -> None:
+        e = self.eng
+        tt = (C.c_double * 16)(*[float(v) for v in np.asarray(t, dtype=np.float64).reshape(16)])
+        e._check(e.lib.pc_transform(e.ctx, _ptr(self.src), self.m, tt, e.stream()), "pc_transform")
+
+    def correspond(self) -> None:
+        e = self.eng
+        e._check(e.lib.pc_knn(e.ctx, self.grid.h, _ptr(self.src), _lib.PC_F64, self.m, 1, -1.0, _ptr(self.idx),
+                              _ptr(self.d2), _lib.PC_F64, None, e.stream()), "pc_knn")
+
+    def terms(self, max_dist: float) -> np.ndarray:
+        e = self.eng
+        out = (C.c_double * 29)()
+        e._check(e.lib.pc_icp_point_to_plane_terms(e.ctx, _ptr(self.src), self.m, _ptr(self.tgt), _lib.PC_F64,
+                                                   _ptr(self.tn), _ptr(self.idx), _ptr(self.d2), _lib.PC_F64,
+                                                   float(max_dist) ** 2, out, e.stream()), "pc_icp_point_to_plane_terms")
+        return np.array(out[:], dtype=np.float64)
+
+    def correspondence_set(self, max_dist: float) -> np.ndarray:
+        idx, d2 = self.idx.cpu().numpy()[:, 0], self.d2.cpu().numpy()[:, 0]
+        rows = np.nonzero((idx >= 0) & (d2 < float(max_dist) ** 2))[0]
+        return np.stack([rows.astype(np.int32), idx[rows]], axis=1)
+
+
 class HipEngine:
     name = "hip"
 
@@ -88,7 +125,7 @@ class HipEngine:
         return torch.empty(shape, dtype=dtype, device=self.device)
 
     def upload(self, a: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        return torch.from_numpy(np.require(a, requirements=["C", "W"])).to(self.device)  # (read-only views are copied)
 
     def dev_points(self, pts: np.ndarray, cache: dict) -> torch.Tensor:
         """Device copy of a cloud's coordinates.  fp32 storage when every coordinate is
@@ -325,6 +362,9 @@ class HipEngine:
         self._check(self.lib.pc_orient_normals(self.ctx, _ptr(t), self._dt(t), _ptr(dn), _ptr(idx), _ptr(cnt), n, int(k),
                                                C.byref(pieces), self.stream()), "pc_orient_normals")
         return dn.cpu().numpy(), int(pieces.value)
+
+    def icp_session(self, src, tgt, tgt_normals) -> HipIcpSession:
+        return HipIcpSession(self, src, tgt, tgt_normals)
 
     def nn_distance(self, pts, cache):
         g = self.grid(pts, cache, 2)

@@ -87,3 +87,30 @@ def test_orient_normals_matches_oracle(hip, oracle, case):
     if case == "two_spheres":
         centre = np.where((np.arange(len(p)) < 6000)[:, None], 0.0, np.array([10.0, 0.0, 0.0]))
         assert (np.einsum("ij,ij->i", got, p - centre) > 0).all()
+
+
+def test_registration_icp_matches_oracle(hip, oracle):
+    """The device ICP loop (search, 6 x 6 reduction, rigid transform) against the numpy statement of the same
+    steps: same correspondences at every iteration, so the same iteration count and, up to the order of the
+    sums, the same transformation."""
+    from oracle.engine import OracleEngine
+    from test_host import _icp_case
+    P.set_engine(OracleEngine())
+    try:
+        source, target, motion = _icp_case(60000, 20000)
+        want = P.registration_icp(source, target, 0.2, max_iteration=30)
+    finally:
+        P.set_engine(hip)
+    got = P.registration_icp(source, target, 0.2, max_iteration=30)
+    assert got.iterations == want.iterations and got.fitness == want.fitness
+    assert np.array_equal(got.correspondence_set, want.correspondence_set)
+    np.testing.assert_allclose(got.transformation, want.transformation, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(got.inlier_rmse, want.inlier_rmse, rtol=1e-9, atol=1e-12)
+    assert np.abs(got.transformation - motion).max() < 2e-3
+    # one step's terms, entry by entry
+    s_dev = hip.icp_session(np.asarray(source.points), np.asarray(target.points), np.asarray(target.normals))
+    s_ref = OracleEngine().icp_session(np.asarray(source.points), np.asarray(target.points), np.asarray(target.normals))
+    for s in (s_dev, s_ref):
+        s.transform(motion)
+        s.correspond()
+    np.testing.assert_allclose(s_dev.terms(0.05), s_ref.terms(0.05), rtol=1e-9, atol=1e-12)

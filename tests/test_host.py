@@ -206,3 +206,32 @@ def test_orient_normals_consistent_tangent_plane(oracle_engine):
     outward = np.einsum("ij,ij->i", n1, p - centre)
     assert (outward > 0).all()
     assert np.allclose(np.abs(np.einsum("ij,ij->i", n1, n0)), 1.0)  # only signs changed
+
+
+def _icp_case(n_target=20000, n_source=6000, seed=3):
+    """A torus with normals, and a part of it moved by a small known rigid motion."""
+    import point_cloud_processing_amd as P
+    from point_cloud_processing_amd.registration import transform_from_vector6
+    rng = np.random.default_rng(seed)
+    tgt = D.torus(n_target, 6)
+    target = P.PointCloud(tgt)
+    target.estimate_normals(P.KDTreeSearchParamKNN(16))
+    motion = transform_from_vector6(np.array([0.02, -0.015, 0.03, 0.01, -0.02, 0.015]))
+    src = tgt[rng.choice(n_target, n_source, replace=False)]
+    src = (src - motion[:3, 3]) @ motion[:3, :3]  # the inverse motion: ICP should find `motion`
+    return P.PointCloud(np.ascontiguousarray(src)), target, motion
+
+
+def test_registration_icp_recovers_motion(oracle_engine):
+    import point_cloud_processing_amd as P
+    source, target, motion = _icp_case()
+    res = P.registration_icp(source, target, 0.2, max_iteration=30)
+    assert res.fitness == 1.0 and res.inlier_rmse < 5e-3 and res.iterations <= 30
+    assert np.abs(res.transformation - motion).max() < 2e-3
+    assert res.correspondence_set.shape == (len(source), 2)
+    # no target normals / nothing to match
+    bare = P.PointCloud(np.asarray(target.points))
+    with pytest.raises(RuntimeError):
+        P.registration_icp(source, bare, 0.2)
+    far = P.registration_icp(P.PointCloud(np.asarray(source.points) + 100.0), target, 0.2, max_iteration=3)
+    assert far.fitness == 0.0 and np.array_equal(far.transformation, np.eye(4)) and len(far.correspondence_set) == 0
