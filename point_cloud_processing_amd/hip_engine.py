@@ -61,7 +61,7 @@ class HipIcpSession:
         self.src = eng.upload(np.asarray(src, dtype=np.float64))
         self.tgt = eng.upload(np.asarray(tgt, dtype=np.float64))
         self.tn = eng.upload(np.asarray(tgt_normals, dtype=np.float64))
-        self.grid = DeviceGrid(eng, self.tgt, len(tgt), 1)
+        self.grid = DeviceGrid(eng, self.tgt, len(tgt), 8)  # cells for 8 neighbours: the source lies off the target (measured best of 1..16)
         self.idx = eng.empty((self.m, 1), torch.int32)
         self.d2 = eng.empty((self.m, 1), torch.float64)
 
