@@ -109,6 +109,12 @@ struct pc_grid {
     mutable int tile_waves = 1;  // waves per workgroup of that kernel
     mutable uint32_t *tile_list = nullptr;  // sparse form: linear ids of the occupied tiles
     mutable int64_t tile_count = 0;
+    // the listed tiles that hold enough points to fill a good part of a wave (made on first need;
+    // full_count < 0: not made yet) and the points they hold
+    mutable uint32_t *full_tiles = nullptr;
+    mutable int64_t full_count = -1;
+    mutable int64_t full_points = 0;
+    mutable std::vector<uint32_t> full_host;  // host copy of full_tiles (ascending): sub-ranges for query shards
     // the same cloud on a 2x coarser grid (and that one's own `coarse`): built for clouds that
     // fill their box unevenly, used by the exact re-run of queries whose surroundings are sparse
     pc_grid *coarse = nullptr;

@@ -889,6 +889,7 @@ void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
         if (g->keys) ctx->release(g->keys);
         if (g->row_start) ctx->release(g->row_start);
         if (g->tile_list) ctx->release(g->tile_list);
+        if (g->full_tiles) ctx->release(g->full_tiles);
         if (g->perm) ctx->release(g->perm);
     }
     delete g;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
             for (int seg = 0; seg < 9; seg++) jn[seg] = 0;
         }
     }
-    if (!A.qflag_in) {  // first pass: how many queries are crowded decides whether finer grids are worth making
+    if (A.count_crowded) {  // how many queries are crowded decides whether finer grids are worth making
         const unsigned long long m = __ballot(crowded);
         if (lane == 0 && m) atomicAdd(A.flag_count + 26, (uint32_t)__popcll(m));
     }

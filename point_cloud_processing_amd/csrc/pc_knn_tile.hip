@@ -21,6 +21,7 @@
 // re-reads served by L2.
 #include <stdio.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "pc_knn_dev.h"
@@ -130,6 +131,77 @@ int build_tile_list_dense(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), nt, reinterpret_cast<int32_t *>(g->tile_list), &nocc, st));
     g->tile_count = nocc;
     return PC_OK;
+}
+
+// flags[i] = listed tile i holds at least `thresh` points; *points += the points of those tiles
+__global__ __launch_bounds__(256) void k_tile_full(GridParams gp, CellIndex ci, int tx, int ty, int tz, int ntx, int nty,
+                                                    const uint32_t *__restrict__ tiles, int64_t m, uint32_t thresh,
+                                                    uint8_t *__restrict__ flags, unsigned long long *__restrict__ points) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t pop = 0;
+    if (i < m) {
+        const int64_t t = tiles[i];
+        const int x0 = (int)(t % ntx) * tx, y0 = (int)((t / ntx) % nty) * ty, z0 = (int)(t / ((int64_t)ntx * nty)) * tz;
+        const int x1 = min(x0 + tx, gp.dim[0]), y1 = min(y0 + ty, gp.dim[1]), z1 = min(z0 + tz, gp.dim[2]);
+        for (int z = z0; z < z1; z++)
+            for (int y = y0; y < y1; y++) {
+                const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+                pop += cell_begin(ci, row + x1) - cell_begin(ci, row + x0);
+            }
+        if (pop < thresh) pop = 0;
+        flags[i] = pop ? 1 : 0;
+    }
+    unsigned long long v = pop;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(points, v);
+}
+
+// g->full_tiles: the listed tiles with at least `thresh` points (once per grid)
+int build_full_tiles(pc_ctx *ctx, const pc_grid *g, uint32_t thresh, hipStream_t st) {
+    if (g->full_count >= 0) return PC_OK;
+    g->full_count = 0;
+    g->full_points = 0;
+    const int64_t m = g->tile_count;
+    if (!g->tile_list || m <= 0) return PC_OK;
+    Scratch flags(ctx, (size_t)m), pick(ctx, sizeof(int32_t) * (size_t)m), pts(ctx, 256);
+    if (!flags.ok() || !pick.ok() || !pts.ok()) return pc_fail(ctx, PC_NOMEM, "full tiles");
+    PC_HIP(hipMemsetAsync(pts.p, 0, sizeof(unsigned long long), st));
+    const int ntx = (g->gp.dim[0] + g->tile[0] - 1) / g->tile[0], nty = (g->gp.dim[1] + g->tile[1] - 1) / g->tile[1];
+    hipLaunchKernelGGL(k_tile_full, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, g->gp, g->index(), g->tile[0],
+                       g->tile[1], g->tile[2], ntx, nty, g->tile_list, m, thresh, flags.as<uint8_t>(),
+                       pts.as<unsigned long long>());
+    int64_t nfull = 0;
+    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), m, pick.as<int32_t>(), &nfull, st));
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(h, pts.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    g->full_points = (int64_t)h[0];
+    if (nfull > 0) {
+        g->full_tiles = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)nfull);
+        if (!g->full_tiles) return pc_fail(ctx, PC_NOMEM, "full tiles");
+        hipLaunchKernelGGL(k_take, dim3((unsigned)((nfull + 255) / 256)), dim3(256), 0, st, g->tile_list, pick.as<int32_t>(),
+                           nfull, g->full_tiles);
+        PC_HIP(hipGetLastError());
+        g->full_host.resize((size_t)nfull);
+        PC_HIP(hipMemcpyAsync(g->full_host.data(), g->full_tiles, sizeof(uint32_t) * (size_t)nfull, hipMemcpyDeviceToHost, st));
+        PC_HIP(hipStreamSynchronize(st));  // (pick goes back to the pool)
+    }
+    g->full_count = nfull;
+    return PC_OK;
+}
+
+// every query of the range open, nothing known about its neighbours yet
+template <typename REC>
+__global__ __launch_bounds__(256) void k_open_range(const REC *__restrict__ rec, int64_t s_begin, int64_t s_end,
+                                                     uint8_t *__restrict__ qflag, float *__restrict__ qub) {
+    const int64_t s = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= s_end) return;
+    double x, y, z;
+    int32_t id;
+    RecTraits<REC>::load(rec + s, x, y, z, id);
+    qflag[id] = 1;
+    qub[id] = INFINITY;
 }
 
 // chooses g->tile / g->tile_cap (once per grid)
@@ -335,7 +407,74 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.cand_cap = l->tile_cap;
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
-        if (batch) {
+        A.count_crowded = i == 0;
+        // First pass of an uneven cloud that the list kernel would take: where the cloud is dense (surfaces
+        // in a sea of clutter) whole tiles are full of queries that share one candidate block, which is the
+        // tile kernel's case (fp32 filter on an LDS block against fp64 distances from global memory).  The
+        // full tiles go first, as a pass over "open" queries; the list kernel then takes what is left.
+        bool mixed = false;
+        // (Measured: 66 M voxels of planes + clutter, k = 32: 348 -> 304 ms; thresholds of 16 to 64 points per
+        // full tile alike.  Small clouds would pay more for the two extra read-backs than they gain.)
+        if (batch && i == 0 && !A.qrec && l->tile_list && !getenv("PC_AMD_NO_MIXED") &&
+            l->n >= (getenv("PC_AMD_MIXED_MIN") ? atoll(getenv("PC_AMD_MIXED_MIN")) : (1ll << 20))) {
+            const uint32_t thresh = getenv("PC_AMD_FULL_TILE") ? (uint32_t)atoi(getenv("PC_AMD_FULL_TILE")) : 32u;
+            PC_TRY(build_full_tiles(ctx, l, thresh, st));
+            mixed = l->full_count > 0 && l->full_points >= l->n / 4;
+        }
+        if (mixed) {
+            const unsigned nbq = (unsigned)((A.nq + 255) / 256);
+            if (g->dtype == PC_F32)
+                hipLaunchKernelGGL(k_open_range<Rec32>, dim3(nbq), dim3(256), 0, st, (const Rec32 *)l->rec, A.s_begin, A.s_end,
+                                   qflag, A.qub_arr);
+            else
+                hipLaunchKernelGGL(k_open_range<Rec64>, dim3(nbq), dim3(256), 0, st, (const Rec64 *)l->rec, A.s_begin, A.s_end,
+                                   qflag, A.qub_arr);
+            A.qflag_in = qflag;
+            A.count_crowded = 0;  // (the list pass below sees every query the tile pass leaves open)
+            // a share of the sorted positions lies in a slab of z cells: only the full tiles of that slab
+            int64_t f0 = 0, f1 = l->full_count;
+            if (A.s_begin > 0 || A.s_end < l->n) {
+                const size_t rb = g->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64);
+                char *hz = reinterpret_cast<char *>(ctx->pinned);
+                PC_HIP(hipMemcpyAsync(hz, (const char *)l->rec + rb * (size_t)A.s_begin, rb, hipMemcpyDeviceToHost, st));
+                PC_HIP(hipMemcpyAsync(hz + 64, (const char *)l->rec + rb * (size_t)(A.s_end - 1), rb, hipMemcpyDeviceToHost, st));
+                PC_HIP(hipStreamSynchronize(st));
+                int64_t tzr[2];
+                for (int e = 0; e < 2; e++) {
+                    const double z = g->dtype == PC_F32 ? (double)reinterpret_cast<const Rec32 *>(hz + 64 * e)->z
+                                                        : reinterpret_cast<const Rec64 *>(hz + 64 * e)->z;
+                    const double t = floor((z - l->gp.o[2]) * l->gp.s);
+                    const int cz = !(t > 0.0) ? 0 : (t >= (double)l->gp.dim[2] ? l->gp.dim[2] - 1 : (int)t);
+                    tzr[e] = cz / l->tile[2];
+                }
+                const uint64_t per_slab = (uint64_t)A.ntile[0] * (uint64_t)A.ntile[1];
+                const uint64_t lo_id = (uint64_t)tzr[0] * per_slab, hi_id = (uint64_t)(tzr[1] + 1) * per_slab;
+                f0 = std::lower_bound(l->full_host.begin(), l->full_host.end(), lo_id,
+                                      [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - l->full_host.begin();
+                f1 = std::lower_bound(l->full_host.begin(), l->full_host.end(), hi_id,
+                                      [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - l->full_host.begin();
+            }
+            A.tile_list = l->full_tiles + f0;
+            const int nw = std::max(1, l->tile_waves);
+            const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+                               sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
+                               nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
+            if (getenv("PC_AMD_DEBUG"))
+                fprintf(stderr, "[pc_amd]   full-tile pass 0: %lld of %lld tiles, %lld of %lld points\n", (long long)l->full_count,
+                        (long long)l->tile_count, (long long)l->full_points, (long long)l->n);
+            if (f1 <= f0) {
+            } else if (g->dtype == PC_F32)
+                pc_tile_launch_f32_split(ks, mode, (unsigned)(f1 - f0), nw, lds, st, A);
+            else
+                pc_tile_launch_f64_split(ks, mode, (unsigned)(f1 - f0), nw, lds, st, A);
+            PC_HIP(hipGetLastError());
+            A.tile_list = l->tile_list;
+            A.count_crowded = 1;
+            int64_t nopen = 0;
+            PC_TRY(pc_batch_open_list(ctx, g->dtype, l->rec, l->n, qflag, open_list, &nopen, st));
+            if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass 0: %lld open queries\n", (long long)nopen);
+            PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
+        } else if (batch) {
             int64_t nopen = A.nq;
             if (i > 0 && list_level == i)
                 nopen = list_count;  // made when the previous pass was counted

@@ -269,7 +269,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         }
         if (!__any(live)) continue;
         if (overfull) {
-            if (too_many && !A.qflag_in) {  // first pass: crowded queries counted (finer grids worth making?)
+            if (too_many && A.count_crowded) {  // crowded queries counted (finer grids worth making?)
                 const unsigned long long m = __ballot(live);
                 if (lane == 0 && m) atomicAdd(A.flag_count + 26, (uint32_t)__popcll(m));
             }

@@ -107,3 +107,25 @@ def test_crowded_patch_gets_finer_levels(hip, oracle):
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
     again = hip.knn(p, None, 12, -1.0, cache)
     assert np.array_equal(again[0], idx) and np.array_equal(again[1], d2)
+
+
+@pytest.mark.parametrize("k", [16, 32])
+def test_mixed_first_pass_agrees(hip, oracle, monkeypatch, k):
+    """Planes + clutter: the first pass split into a tile pass over the full tiles and the open-query list
+    for the rest (taken by default only from a million points up; forced here), for the whole cloud and for
+    the shares of three ranks, against the oracle."""
+    p = D.planar_patches(400_000, 5, extent=60.0, n_patches=12)
+    ridx, rd2, rcnt = oracle.Grid(p).knn_self(k)
+    monkeypatch.setenv("PC_AMD_MIXED_MIN", "0")
+    monkeypatch.setenv("PC_AMD_FULL_TILE", "8")
+    monkeypatch.setenv("PC_AMD_DEBUG", "1")
+    cache = {}
+    idx, d2, cnt, avg, nrm = hip.knn_fused(p, k, -1.0, cache)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
+    np.testing.assert_allclose(avg, np.sqrt(rd2).sum(1) / k, rtol=1e-13)
+    seen = np.zeros(len(p), dtype=int)
+    for r in range(3):
+        owned, sidx, sd2, scnt = hip.knn_shard(p, k, -1.0, cache, r, 3)
+        assert np.array_equal(sidx, ridx[owned]) and np.array_equal(sd2, rd2[owned]) and np.array_equal(scnt, rcnt[owned])
+        seen[owned] += 1
+    assert (seen == 1).all()
