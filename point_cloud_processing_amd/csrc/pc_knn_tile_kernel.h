@@ -98,7 +98,7 @@ struct TileRec<Rec64> {
 // One tile (first cell c0, extent ext cells) answered by the whole workgroup.  Returns 1, having done
 // nothing, if the tile's block holds more candidates than LDS and may_split allows the caller to come
 // back with smaller tiles; 0 otherwise.  Every return is uniform over the workgroup.
-template <typename REC, int KS, int MODE>
+template <typename REC, int KS, int MODE, bool UNEVEN>
 __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const int (&c0)[3], const int (&ext)[3],
                                          const bool may_split) {
     __syncthreads();  // a previous call of this workgroup is done with LDS
@@ -358,8 +358,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         // A query with fewer than 2 k candidates in its 27 cells will not find k of them inside the reach of
         // those cells (a ball inscribed in the block holds a fifth of an evenly filled block's points, under
         // half of a surface's): it is handed on without costing the wave any steps.  (Not when the 27 cells
-        // are the whole grid or a radius limits the search: few neighbours are the answer then.)
-        {
+        // are the whole grid or a radius limits the search: few neighbours are the answer then.  Levels of
+        // uneven clouds only: an evenly filled grid has no such queries to speak of.)
+        if (UNEVEN) {
             uint32_t total = 0;
             bool whole_grid = true;
 #pragma unroll
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
     const int c0[3] = {tx * A.tile[0], ty * A.tile[1], tz * A.tile[2]};  // first cell of the tile
     const int ext[3] = {A.tile[0], A.tile[1], A.tile[2]};
     if (!SPLIT) {  // (clouds that fill their box: the tile shape was sized for the LDS capacity)
-        tile_body<REC, KS, MODE>(A, smem, c0, ext, false);
+        tile_body<REC, KS, MODE, false>(A, smem, c0, ext, false);
         return;
     }
     // The whole tile first; if its block is too full for LDS, its (up to) eight half-size parts
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs
             empty |= sext[a] <= 0 || sc0[a] >= A.gp.dim[a];
         }
         if (empty) continue;
-        const int again = tile_body<REC, KS, MODE>(A, smem, sc0, sext, sub < 0);
+        const int again = tile_body<REC, KS, MODE, true>(A, smem, sc0, sext, sub < 0);
         if (sub < 0) {
             if (!again) break;
             nsub = 8;
