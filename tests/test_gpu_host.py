@@ -114,3 +114,33 @@ def test_registration_icp_matches_oracle(hip, oracle):
         s.transform(motion)
         s.correspond()
     np.testing.assert_allclose(s_dev.terms(0.05), s_ref.terms(0.05), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7])
+def test_orient_normals_tiny_clouds(hip, oracle, n):
+    """Fewer points than neighbours asked for: rows are short, every piece still gets its seed."""
+    rng = np.random.default_rng(n)
+    p = np.ascontiguousarray(rng.random((n, 3)).astype(np.float32).astype(np.float64))
+    nrm = rng.standard_normal((n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    k = max(2, min(50, n))
+    idx, _, cnt = oracle.knn(p, None, k, None)
+    want, pieces = oracle.orient_normals(p, nrm, idx, cnt)
+    got, got_pieces = hip.orient_normals(p, nrm, k, {})
+    assert got_pieces == pieces == 1 and np.array_equal(got, want)
+    assert got[np.argmax(p[:, 2]), 2] >= 0.0
+
+
+def test_new_entry_points_reject_bad_arguments(hip):
+    import ctypes as C
+    lib, ctx = hip.lib, hip.ctx
+    one = C.c_int64(0)
+    assert lib.pc_orient_normals(ctx, None, 0, None, None, None, 5, 4, C.byref(one), None) != 0   # null buffers
+    assert lib.pc_orient_normals(ctx, None, 0, None, None, None, 0, 4, C.byref(one), None) == 0   # empty cloud
+    assert lib.pc_orient_normals(ctx, None, 7, None, None, None, 0, 4, C.byref(one), None) != 0   # unknown dtype
+    assert lib.pc_orient_normals(ctx, None, 0, None, None, None, 0, 0, C.byref(one), None) != 0   # k < 1
+    out = (C.c_double * 29)()
+    assert lib.pc_icp_point_to_plane_terms(ctx, None, 3, None, 0, None, None, None, 0, 1.0, out, None) != 0
+    assert lib.pc_icp_point_to_plane_terms(ctx, None, 0, None, 0, None, None, None, 0, 1.0, out, None) == 0
+    assert lib.pc_transform(ctx, None, 4, None, None) != 0
+    assert b"pc_transform" in lib.pc_last_error(ctx)
