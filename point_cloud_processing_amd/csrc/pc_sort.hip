@@ -164,23 +164,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint32_t
 
 // one block scans up to a few hundred thousand block sums in place
 __global__ __launch_bounds__(1024) void k_scan_single(uint32_t *__restrict__ data, int64_t n) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[16];
     int64_t per = (n + 1023) / 1024;
     int64_t b = (int64_t)threadIdx.x * per, e = b + per < n ? b + per : n;
     uint32_t s = 0;
     for (int64_t i = b; i < e; i++) s += data[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int i = 0; i < 1024; i++) {
-            uint32_t t = part[i];
-            part[i] = acc;
-            acc += t;
-        }
+    // exclusive scan of the 1024 partial sums: inclusive wave scans, then the 16 wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
     }
+    if (lane == 63) part[wave] = x;
     __syncthreads();
-    uint32_t acc = part[threadIdx.x];
+    uint32_t acc = x - s;
+    for (int w = 0; w < wave; w++) acc += part[w];
     for (int64_t i = b; i < e; i++) {
         uint32_t t = data[i];
         data[i] = acc;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t *__restric
         v[j] = base + j < n ? data[base + j] : 0;
         s += v[j];
     }
-    uint32_t off = block_exclusive_scan(s, nullptr, lds) + sums[blockIdx.x];
+    uint32_t off = block_exclusive_scan(s, nullptr, lds) + (sums ? sums[blockIdx.x] : 0u);
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         if (base + j < n) data[base + j] = off;
@@ -248,6 +248,11 @@ __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *__
 int pc_exclusive_scan_u32(pc_ctx *ctx, uint32_t *data, int64_t n, hipStream_t st) {
     if (n <= 0) return PC_OK;
     int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb == 1) {  // one block's worth: one kernel
+        hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(SCAN_THREADS), 0, st, data, n, (const uint32_t *)nullptr);
+        PC_HIP(hipGetLastError());
+        return PC_OK;
+    }
     Scratch sums(ctx, sizeof(uint32_t) * (size_t)nb);
     if (!sums.ok()) return pc_fail(ctx, PC_NOMEM, "scan scratch");
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, st, data, n,
