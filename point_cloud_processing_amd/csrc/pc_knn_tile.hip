@@ -261,6 +261,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         if (const char *e = getenv(g->level > 0 ? "PC_AMD_UNEVEN_TILE1" : "PC_AMD_UNEVEN_TILE0")) base = std::max(1, atoi(e));
         for (int a = 0; a < 3; a++) best[a] = std::min(std::min(base, a == 0 ? MAX_NX - 2 : 6), std::max(1, (int)g->gp.dim[a]));
         expect = UNEVEN_CAP;
+        waves = 1;  // (passes over few tiles take two: uneven_waves below)
     }
     int cap = ((int)expect + 63) / 64 * 64;
     g->tile_cap = std::min(CAND_CAP_MAX, std::max(256, cap));
@@ -291,6 +292,15 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         for (int a = 0; a < 3; a++) g->tile[a] = t2[a];
     }
     return PC_OK;
+}
+
+// Waves per tile of an uneven level's pass.  With few tiles the fullest ones (hundreds of queries next to
+// a LiDAR sensor) set the length of the pass and a second wave halves it (config 3 frame: 2.21 -> 1.94 ms);
+// with many tiles the GPU is full either way and the second wave only costs LDS (66 M voxels of planes +
+// clutter: 304 -> 326 ms).  Four waves measured slower everywhere.
+int uneven_waves(int64_t tiles) {
+    if (const char *e = getenv("PC_AMD_UNEVEN_WAVES")) return std::min(MAX_TILE_WAVES, std::max(1, atoi(e)));
+    return tiles < 32768 ? 2 : 1;
 }
 
 // After the multi-level passes: the points still flagged, as (sorted position at level 0, bound).
@@ -455,7 +465,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                                       [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - l->full_host.begin();
             }
             A.tile_list = l->full_tiles + f0;
-            const int nw = std::max(1, l->tile_waves);
+            const int nw = uneven_waves(f1 - f0);
             const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
                                sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
                                nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
@@ -484,7 +494,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, i > 0 ? open_list : nullptr, nopen, st));
         } else {
             if (nt <= 0) continue;
-            const int nw = std::max(1, l->tile_waves);
+            const int nw = l->uneven ? uneven_waves(nt) : std::max(1, l->tile_waves);
             if (getenv("PC_AMD_DEBUG"))
                 fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],
                         l->tile[2], l->tile_cap, nw, (long long)nt);
