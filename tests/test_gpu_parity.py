@@ -301,3 +301,34 @@ def test_query_shards_cover_and_agree(hip, oracle, world):
         assert np.array_equal(idx, ridx[owned]) and np.array_equal(d2, rd2[owned]) and np.array_equal(cnt, rcnt[owned])
         seen[owned] += 1
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("case", ["all_duplicates", "collinear", "coplanar_lattice", "far_offset_fp64", "two_far_clusters",
+                                  "one_outlier_far_away"])
+def test_knn_pathological_shapes(hip, oracle, case):
+    """Clouds that stress the index rather than the arithmetic: zero extent, one- and two-dimensional clouds,
+    coordinates with a huge common offset (fp64 records), an extent many orders above the point spacing."""
+    rng = np.random.default_rng(101)
+    if case == "all_duplicates":
+        p = np.tile(np.array([[0.25, -1.5, 3.0]]), (5000, 1))
+    elif case == "collinear":
+        p = np.outer(rng.random(20000), np.array([1.0, 2.0, -0.5]))
+    elif case == "coplanar_lattice":
+        gx, gy = np.meshgrid(np.arange(120.0), np.arange(120.0))
+        p = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 7.0)], 1)
+    elif case == "far_offset_fp64":
+        p = rng.random((30000, 3)) * 0.01 + np.array([1.0e6, -2.0e6, 3.0e5])
+    elif case == "two_far_clusters":
+        p = np.concatenate([rng.normal(0, 0.001, (20000, 3)), rng.normal(0, 0.001, (20000, 3)) + 5.0e4])
+    else:
+        p = np.concatenate([rng.random((40000, 3)), np.array([[1.0e7, 1.0e7, 1.0e7]])])
+    if case != "far_offset_fp64":
+        p = p.astype(np.float32).astype(np.float64)
+    p = np.ascontiguousarray(p)
+    for k in (1, 8, 20):
+        idx, d2, cnt = hip.knn(p, None, k, -1.0, {})
+        ridx, rd2, rcnt = oracle.knn(p, None, k)
+        assert np.array_equal(cnt, rcnt) and np.array_equal(idx, ridx) and np.array_equal(d2, rd2), (case, k)
+    avg = hip.sor_avg_dev(p, 8, {}).cpu().numpy()
+    np.testing.assert_allclose(avg, oracle.sor_avg(p, 8), rtol=1e-13, atol=0)
+    np.testing.assert_array_equal(hip.nn_distance(p, {}), oracle.nn_distance(p))
