@@ -3,8 +3,8 @@
 // Open3D's TransformationEstimationPointToPlane::ComputeTransformation):
 //   pc_icp_point_to_plane_terms  the 6x6 normal equations of one linearised step, reduced on the device
 //   pc_transform                 p <- R p + t over a cloud, in place
-// Sums have a fixed shape (each thread a fixed stride of the correspondences, block partials added in
-// block order), so a given input always gives the same bits.
+// Sums have a fixed shape (each thread a fixed stride of the correspondences, block partials added by one
+// wave in a fixed order), so a given input always gives the same bits.
 #include "pc_common.h"
 
 namespace {
@@ -54,11 +54,14 @@ __global__ __launch_bounds__(256) void k_icp_terms(const double *__restrict__ sr
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// one wave per term: lane j adds the block partials j, j + 64, ... in that order, then a fixed shuffle tree
 __global__ __launch_bounds__(64) void k_icp_final(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
-    if (threadIdx.x >= ICP_TERMS) return;
+    const int term = blockIdx.x;
     double v = 0.0;
-    for (int b = 0; b < nblocks; b++) v += partial[(int64_t)b * ICP_TERMS + threadIdx.x];
-    out[threadIdx.x] = v;
+    for (int b = threadIdx.x; b < nblocks; b += 64) v += partial[(int64_t)b * ICP_TERMS + term];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (threadIdx.x == 0) out[term] = v;
 }
 
 struct Rigid {
@@ -100,7 +103,7 @@ int pc_icp_point_to_plane_terms(pc_ctx *ctx, const double *src_dev, int64_t m, c
     else
         hipLaunchKernelGGL(k_icp_terms<double>, dim3(nb), dim3(256), 0, st, src_dev, m, (const double *)tgt_xyz_dev,
                            tgt_normals_dev, corr_idx_dev, corr_d2_dev, d2_dtype == PC_F64, max_d2, partial.as<double>());
-    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(64), 0, st, partial.as<double>(), nb, fin);
+    hipLaunchKernelGGL(k_icp_final, dim3(ICP_TERMS), dim3(64), 0, st, partial.as<double>(), nb, fin);
     PC_HIP(hipGetLastError());
     double *host = reinterpret_cast<double *>(ctx->pinned);
     PC_HIP(hipMemcpyAsync(host, fin, sizeof(double) * ICP_TERMS, hipMemcpyDeviceToHost, st));

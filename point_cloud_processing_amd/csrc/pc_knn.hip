@@ -237,15 +237,22 @@ __global__ __launch_bounds__(256) void k_sor_reduce(const double *__restrict__ a
     }
 }
 
-__global__ void k_sor_reduce_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
-    if (threadIdx.x != 0) return;
+// one wave: lane j adds the partials j, j + 64, ... in that order, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void k_sor_reduce_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
     double s = 0.0, c = 0.0;
-    for (int b = 0; b < nb; b++) {
+    for (int b = threadIdx.x; b < nb; b += 64) {
         s += part[2 * b];
         c += part[2 * b + 1];
     }
-    out[0] = s;
-    out[1] = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        c += __shfl_down(c, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        out[1] = c;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sor_flags(const double *__restrict__ avg, int64_t n, double thr,
