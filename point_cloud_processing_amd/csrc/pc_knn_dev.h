@@ -268,6 +268,58 @@ __device__ inline void fast_eigen3x3(const double cov[6], double out[3]) {
 }
 
 
+// sums of x, y, z, xx, xy, xz, yy, yz, zz over the neighbours, nearest first (Open3D's ComputeCovariance)
+__device__ inline void cumulant_add(double (&cu)[9], double px, double py, double pz) {
+    cu[0] += px;
+    cu[1] += py;
+    cu[2] += pz;
+    cu[3] += px * px;
+    cu[4] += px * py;
+    cu[5] += px * pz;
+    cu[6] += py * py;
+    cu[7] += py * pz;
+    cu[8] += pz * pz;
+}
+
+// the normal of one query from the cumulants of its cnt neighbours (cu is used up)
+template <int MODE>
+__device__ inline void emit_normal(const ScanArgs &A, int64_t out_row, int cnt, double (&cu)[9]) {
+    {
+        double *out_n = MODE == M_ALL ? A.out_nrm : A.out_f64;
+        double nv[3];
+        if (cnt >= 3) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) cu[i] /= (double)cnt;
+            double cov[6];
+            cov[0] = cu[3] - cu[0] * cu[0];
+            cov[3] = cu[6] - cu[1] * cu[1];
+            cov[5] = cu[8] - cu[2] * cu[2];
+            cov[1] = cu[4] - cu[0] * cu[1];
+            cov[2] = cu[5] - cu[0] * cu[2];
+            cov[4] = cu[7] - cu[1] * cu[2];
+            fast_eigen3x3(cov, nv);
+        } else {
+            nv[0] = 0, nv[1] = 0, nv[2] = 1;  // identity covariance -> smallest-diagonal rule -> +z
+        }
+        const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        if (nn == 0.0) {
+            if (A.prior) {
+                nv[0] = A.prior[3 * out_row], nv[1] = A.prior[3 * out_row + 1], nv[2] = A.prior[3 * out_row + 2];
+            } else {
+                nv[0] = 0, nv[1] = 0, nv[2] = 1;
+            }
+        }
+        if (A.prior &&
+            nv[0] * A.prior[3 * out_row] + nv[1] * A.prior[3 * out_row + 1] + nv[2] * A.prior[3 * out_row + 2] < 0.0) {
+            nv[0] *= -1.0, nv[1] *= -1.0, nv[2] *= -1.0;
+        }
+        out_n[3 * out_row] = nv[0];
+        out_n[3 * out_row + 1] = nv[1];
+        out_n[3 * out_row + 2] = nv[2];
+    }
+}
+
+
 // ---- per-query consumers -------------------------------------------------------------------------
 // NB(s, d2, x, y, z, idx) yields the s-th nearest neighbour (ascending (d2, idx)) of this query.
 // ONLY_NORMALS: the caller has written the rows / mean distance itself.
@@ -313,52 +365,16 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
         A.out_f64[out_row] = d;
     }
     if (MODE == M_NORMALS || (MODE == M_ALL && A.out_nrm)) {
-        double *out_n = MODE == M_ALL ? A.out_nrm : A.out_f64;
-        double nv[3];
+        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (cnt >= 3) {
-            double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int s = 0; s < cnt; s++) {
                 double d, px, py, pz;
                 int32_t id;
                 nb(s, d, px, py, pz, id);
-                cu[0] += px;
-                cu[1] += py;
-                cu[2] += pz;
-                cu[3] += px * px;
-                cu[4] += px * py;
-                cu[5] += px * pz;
-                cu[6] += py * py;
-                cu[7] += py * pz;
-                cu[8] += pz * pz;
-            }
-#pragma unroll
-            for (int i = 0; i < 9; i++) cu[i] /= (double)cnt;
-            double cov[6];
-            cov[0] = cu[3] - cu[0] * cu[0];
-            cov[3] = cu[6] - cu[1] * cu[1];
-            cov[5] = cu[8] - cu[2] * cu[2];
-            cov[1] = cu[4] - cu[0] * cu[1];
-            cov[2] = cu[5] - cu[0] * cu[2];
-            cov[4] = cu[7] - cu[1] * cu[2];
-            fast_eigen3x3(cov, nv);
-        } else {
-            nv[0] = 0, nv[1] = 0, nv[2] = 1;  // identity covariance -> smallest-diagonal rule -> +z
-        }
-        const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-        if (nn == 0.0) {
-            if (A.prior) {
-                nv[0] = A.prior[3 * out_row], nv[1] = A.prior[3 * out_row + 1], nv[2] = A.prior[3 * out_row + 2];
-            } else {
-                nv[0] = 0, nv[1] = 0, nv[2] = 1;
+                cumulant_add(cu, px, py, pz);
             }
         }
-        if (A.prior &&
-            nv[0] * A.prior[3 * out_row] + nv[1] * A.prior[3 * out_row + 1] + nv[2] * A.prior[3 * out_row + 2] < 0.0) {
-            nv[0] *= -1.0, nv[1] *= -1.0, nv[2] *= -1.0;
-        }
-        out_n[3 * out_row] = nv[0];
-        out_n[3 * out_row + 1] = nv[1];
-        out_n[3 * out_row + 2] = nv[2];
+        emit_normal<MODE>(A, out_row, cnt, cu);
     }
 }
 

@@ -607,6 +607,26 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             A.out_f64[qid] = cnt > 1 ? sqrt(dd[1]) : 0.0;
             continue;
         }
+        if (DIRECT && (MODE == M_NORMALS || MODE == M_ALL)) {
+            // normals of the short lists: the cumulants straight from the sorted registers (same order of
+            // additions as the generic consumer), all candidate reads in flight at once
+            if (MODE == M_NORMALS || A.out_nrm) {
+                double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (cnt >= 3) {
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        if (s < cnt) {
+                            double x, y, z;
+                            int32_t nid;
+                            TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2], cws[od[s]]), x, y, z, nid);
+                            cumulant_add(cu, x, y, z);
+                        }
+                    }
+                }
+                emit_normal<MODE>(A, (int64_t)qid, cnt, cu);
+            }
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < KS; s++)
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
