@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,9 @@ struct pc_ctx {
     std::vector<Block> pool;
     size_t pool_bytes = 0;
     void *pinned = nullptr;  // 4 KiB of page-locked host memory for small device-to-host readbacks
+    // Entry points of the C ABI hold this for their whole call: the app's filter and reconstruction workers
+    // (two threads, app/Controllers/app_controller.py:428-441 and 528-543) may call into one context at once.
+    std::recursive_mutex mu;
 
     void *alloc(size_t bytes);
     void release(void *p);
@@ -31,6 +35,18 @@ struct pc_ctx {
 };
 
 int pc_fail(pc_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+
+struct PcLock {
+    pc_ctx *c;
+    explicit PcLock(pc_ctx *ctx) : c(ctx) {
+        if (c) c->mu.lock();
+    }
+    ~PcLock() {
+        if (c) c->mu.unlock();
+    }
+    PcLock(const PcLock &) = delete;
+    PcLock &operator=(const PcLock &) = delete;
+};
 
 #define PC_HIP(call)                                                            \
     do {                                                                        \

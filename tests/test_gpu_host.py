@@ -144,3 +144,39 @@ def test_new_entry_points_reject_bad_arguments(hip):
     assert lib.pc_icp_point_to_plane_terms(ctx, None, 0, None, 0, None, None, None, 0, 1.0, out, None) == 0
     assert lib.pc_transform(ctx, None, 4, None, None) != 0
     assert b"pc_transform" in lib.pc_last_error(ctx)
+
+
+def test_two_threads_share_one_engine(hip, oracle):
+    """The app's filter and reconstruction workers run in two threads (app_controller.py:428-441, 528-543) and
+    reach the same engine: concurrent calls on one context must give what they give one after the other."""
+    import threading
+    a = D.gaussian_clusters(60000, 41)
+    b = D.bumpy_sphere(50000, 42)
+    want_a = oracle.knn(a, None, 16)
+    want_b = oracle.sor_avg(b, 20)
+    errors = []
+
+    def work_a():
+        try:
+            for _ in range(6):
+                idx, d2, cnt = hip.knn(a, None, 16, -1.0, {})
+                assert np.array_equal(idx, want_a[0]) and np.array_equal(d2, want_a[1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def work_b():
+        try:
+            for _ in range(6):
+                avg = hip.sor_avg_dev(b, 20, {}).cpu().numpy()
+                np.testing.assert_allclose(avg, want_b, rtol=1e-13)
+                vp, _, _ = hip.voxel_downsample(b, None, None, 0.01, {})
+                assert len(vp) > 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=work_a), threading.Thread(target=work_b)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
