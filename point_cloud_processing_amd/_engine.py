@@ -6,15 +6,20 @@ is no CPU fallback.  ``set_engine`` exists so that test code can inject a checke
 """
 from __future__ import annotations
 
+import threading
+
 _active = None
+_lock = threading.Lock()  # the app's worker threads may ask for the engine at the same moment
 
 
 def get():
     global _active
     if _active is None:
-        from .hip_engine import HipEngine  # raises if the HIP library / device is absent
+        with _lock:
+            if _active is None:
+                from .hip_engine import HipEngine  # raises if the HIP library / device is absent
 
-        _active = HipEngine()
+                _active = HipEngine()
     return _active
 
 
