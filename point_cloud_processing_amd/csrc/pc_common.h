@@ -28,6 +28,11 @@ struct pc_ctx {
     // Entry points of the C ABI hold this for their whole call: the app's filter and reconstruction workers
     // (two threads, app/Controllers/app_controller.py:428-441 and 528-543) may call into one context at once.
     std::recursive_mutex mu;
+    // The stream of the previous call: pooled blocks go back to the pool when a call returns, on the
+    // understanding that the next user is ordered behind it on the same stream.  A call that arrives on
+    // another stream waits for the previous one first.
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
 
     void *alloc(size_t bytes);
     void release(void *p);
@@ -40,6 +45,17 @@ struct PcLock {
     pc_ctx *c;
     explicit PcLock(pc_ctx *ctx) : c(ctx) {
         if (c) c->mu.lock();
+    }
+    PcLock(pc_ctx *ctx, void *stream) : c(ctx) {
+        if (!c) return;
+        c->mu.lock();
+        const hipStream_t st = (hipStream_t)stream;
+        if (c->has_last_stream && c->last_stream != st) {
+            (void)hipSetDevice(c->device);
+            (void)hipStreamSynchronize(c->last_stream);
+        }
+        c->last_stream = st;
+        c->has_last_stream = true;
     }
     ~PcLock() {
         if (c) c->mu.unlock();

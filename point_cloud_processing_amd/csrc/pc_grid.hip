@@ -484,7 +484,7 @@ extern "C" {
 
 int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_min[3], double out_max[3],
             void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !out_min || !out_max || n < 0 || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
         return pc_fail(ctx, PC_BAD_ARG, "pc_bbox");
     PC_HIP(hipSetDevice(ctx->device));
@@ -493,7 +493,7 @@ int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_m
 
 int pc_affine(pc_ctx *ctx, double *xyz_dev, int64_t n, const double *t, int has_scale, double s, const double *c,
               void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || n < 0 || (n > 0 && !xyz_dev) || (has_scale && !c)) return pc_fail(ctx, PC_BAD_ARG, "pc_affine");
     PC_HIP(hipSetDevice(ctx->device));
     if (n == 0) return PC_OK;
@@ -512,7 +512,7 @@ int pc_affine(pc_ctx *ctx, double *xyz_dev, int64_t n, const double *t, int has_
 
 int pc_voxel_assign(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double voxel_size, int32_t *out_ijk_dev,
                     int32_t out_dims[3], void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || n < 0 || (n > 0 && (!xyz_dev || !out_ijk_dev)) || (dtype != PC_F32 && dtype != PC_F64))
         return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_assign");
     if (!(voxel_size > 0.0)) return pc_fail(ctx, PC_BAD_ARG, "voxel_size <= 0.");
@@ -543,7 +543,7 @@ int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const doubl
                         const double *colors_dev, int64_t n, double voxel_size, double *out_xyz_dev,
                         double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
                         int32_t *out_ijk_dev, int64_t *out_m, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !out_m || n < 0 || n >= INT32_MAX || (n > 0 && (!xyz_dev || !out_xyz_dev)) ||
         (dtype != PC_F32 && dtype != PC_F64))
         return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_downsample");
@@ -593,7 +593,7 @@ int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const doubl
 
 int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double cell_size, int k_hint, pc_grid **out,
                   void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !out || n < 0 || n >= INT32_MAX || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
         return pc_fail(ctx, PC_BAD_ARG, "pc_grid_build");
     PC_HIP(hipSetDevice(ctx->device));
@@ -915,7 +915,7 @@ int pc_grid_info(const pc_grid *g, double info[6]) {
 const int32_t *pc_grid_perm_dev(const pc_grid *g) { return g ? g->perm : nullptr; }
 
 int pc_grid_perm_copy(pc_ctx *ctx, const pc_grid *g, int64_t s_begin, int64_t s_end, int32_t *out_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !g || s_begin < 0 || s_end < s_begin || s_end > g->n || (s_end > s_begin && !out_dev))
         return pc_fail(ctx, PC_BAD_ARG, "pc_grid_perm_copy");
     PC_HIP(hipSetDevice(ctx->device));
@@ -927,7 +927,7 @@ int pc_grid_perm_copy(pc_ctx *ctx, const pc_grid *g, int64_t s_begin, int64_t s_
 
 int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
                    void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || m < 0 || (m > 0 && (!src_dev || !idx_dev || !dst_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_gather_rows");
     PC_HIP(hipSetDevice(ctx->device));
     if (m == 0) return PC_OK;

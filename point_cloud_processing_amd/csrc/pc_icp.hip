@@ -85,7 +85,7 @@ extern "C" {
 int pc_icp_point_to_plane_terms(pc_ctx *ctx, const double *src_dev, int64_t m, const void *tgt_xyz_dev, int tgt_dtype,
                                 const double *tgt_normals_dev, const int32_t *corr_idx_dev, const void *corr_d2_dev,
                                 int d2_dtype, double max_d2, double out_terms[29], void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !out_terms || m < 0 || (tgt_dtype != PC_F32 && tgt_dtype != PC_F64) ||
         (d2_dtype != PC_F32 && d2_dtype != PC_F64) ||
         (m > 0 && (!src_dev || !tgt_xyz_dev || !tgt_normals_dev || !corr_idx_dev || !corr_d2_dev)))
@@ -114,7 +114,7 @@ int pc_icp_point_to_plane_terms(pc_ctx *ctx, const double *src_dev, int64_t m, c
 }
 
 int pc_transform(pc_ctx *ctx, double *xyz_dev, int64_t n, const double T[16], void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !T || n < 0 || (n > 0 && !xyz_dev)) return pc_fail(ctx, PC_BAD_ARG, "pc_transform");
     PC_HIP(hipSetDevice(ctx->device));
     if (n == 0) return PC_OK;

@@ -292,7 +292,7 @@ extern "C" {
 
 int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype, int64_t nq, int k, double radius,
            int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || k < 1 || k > PC_MAX_K || nq < 0) return pc_fail(ctx, PC_BAD_ARG, "pc_knn");
     if (!queries_dev) return pc_knn_range(ctx, grid, 0, grid->n, k, radius, out_idx_dev, out_d2_dev, d2_dtype,
                                           out_cnt_dev, stream);
@@ -324,7 +324,7 @@ int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype
 
 int pc_knn_range(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
                  int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || k < 1 || k > PC_MAX_K || !range_ok(grid, s_begin, s_end))
         return pc_fail(ctx, PC_BAD_ARG, "pc_knn_range");
     PC_HIP(hipSetDevice(ctx->device));
@@ -342,7 +342,7 @@ int pc_knn_range(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_en
 
 int pc_sor_avg(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double *out_avg_dev,
                void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || k < 1 || k > PC_MAX_K || !range_ok(grid, s_begin, s_end) || (s_end > s_begin && !out_avg_dev))
         return pc_fail(ctx, PC_BAD_ARG, "pc_sor_avg");
     PC_HIP(hipSetDevice(ctx->device));
@@ -357,7 +357,7 @@ int pc_sor_avg(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end,
 int pc_knn_fused(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
                  int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, double *out_avg_dev,
                  double *out_normals_dev, const double *prior_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || k < 1 || k > PC_MAX_K || !range_ok(grid, s_begin, s_end))
         return pc_fail(ctx, PC_BAD_ARG, "pc_knn_fused");
     PC_HIP(hipSetDevice(ctx->device));
@@ -377,7 +377,7 @@ int pc_knn_fused(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_en
 }
 
 int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, int64_t *n_valid, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || n < 0 || (n > 0 && !avg_dev) || !sum_pos || !n_valid) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_sum");
     PC_HIP(hipSetDevice(ctx->device));
     double o[2];
@@ -388,7 +388,7 @@ int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, i
 }
 
 int pc_sor_sqsum(pc_ctx *ctx, const double *avg_dev, int64_t n, double mean, double *sq, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || n < 0 || (n > 0 && !avg_dev) || !sq) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_sqsum");
     PC_HIP(hipSetDevice(ctx->device));
     double o[2];
@@ -399,7 +399,7 @@ int pc_sor_sqsum(pc_ctx *ctx, const double *avg_dev, int64_t n, double mean, dou
 
 int pc_sor_select(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshold, uint8_t *out_mask_dev,
                   int32_t *out_kept_dev, int64_t *n_kept, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || n < 0 || (n > 0 && !avg_dev) || !n_kept) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_select");
     PC_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -415,7 +415,7 @@ int pc_sor_select(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshol
 
 int pc_normals(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
                const double *prior_dev, double *out_normals_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || k < 1 || k > PC_MAX_K || !range_ok(grid, s_begin, s_end) ||
         (s_end > s_begin && !out_normals_dev))
         return pc_fail(ctx, PC_BAD_ARG, "pc_normals");
@@ -432,7 +432,7 @@ int pc_normals(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end,
 
 int pc_radius_count(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype, int64_t nq,
                     int64_t s_begin, int64_t s_end, double radius, int32_t *out_cnt_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || !(radius >= 0) || !out_cnt_dev) return pc_fail(ctx, PC_BAD_ARG, "pc_radius_count");
     PC_HIP(hipSetDevice(ctx->device));
     ScanArgs A = base_args(grid);
@@ -452,7 +452,7 @@ int pc_radius_count(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, i
 }
 
 int pc_nn_distance(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, double *out_dev, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || !grid || !range_ok(grid, s_begin, s_end) || (s_end > s_begin && !out_dev))
         return pc_fail(ctx, PC_BAD_ARG, "pc_nn_distance");
     PC_HIP(hipSetDevice(ctx->device));

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_orient_apply(double *__restrict__ nrm, 
 extern "C" int pc_orient_normals(pc_ctx *ctx, const void *xyz_dev, int dtype, double *normals_dev,
                                  const int32_t *knn_idx_dev, const int32_t *knn_cnt_dev, int64_t n, int k,
                                  int64_t *out_pieces, void *stream) {
-    PcLock lock(ctx);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
     if (!ctx || n < 0 || k < 1 || (dtype != PC_F32 && dtype != PC_F64) ||
         (n > 0 && (!xyz_dev || !normals_dev || !knn_idx_dev)))
         return pc_fail(ctx, PC_BAD_ARG, "pc_orient_normals");

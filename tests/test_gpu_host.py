@@ -180,3 +180,16 @@ def test_two_threads_share_one_engine(hip, oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_calls_alternate_between_streams(hip, oracle):
+    """Pooled scratch is handed from call to call in stream order; a call on another stream waits for the
+    previous stream first, so alternating streams changes nothing."""
+    import torch
+    p = D.gaussian_clusters(80000, 51)
+    want = oracle.knn(p, None, 16)
+    s1, s2 = torch.cuda.Stream(device=hip.device), torch.cuda.Stream(device=hip.device)
+    for it in range(6):
+        with torch.cuda.stream(s1 if it % 2 == 0 else s2):
+            idx, d2, cnt = hip.knn(p, None, 16, -1.0, {})
+        assert np.array_equal(idx, want[0]) and np.array_equal(d2, want[1])
