@@ -125,6 +125,7 @@ struct pc_grid {
     int64_t n = 0;
     int dtype = PC_F32;
     GridParams gp{};
+    double bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};  // the cloud's bounding box
     void *rec = nullptr;          // Rec32[n] or Rec64[n]
     uint32_t *cell_start = nullptr;  // ncell + 1 (dense form), or NULL
     uint32_t *keys = nullptr;        // n sorted cell keys (sparse form), or NULL

@@ -337,17 +337,6 @@ __global__ __launch_bounds__(256) void k_run_stats(const uint32_t *__restrict__ 
     }
 }
 
-// the inverse of k_gather_records: coordinates back at their original index
-template <typename T, typename REC>
-__global__ __launch_bounds__(256) void k_scatter_coords(const REC *__restrict__ rec, int64_t n, T *__restrict__ xyz) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const REC r = rec[i];
-    xyz[3 * (size_t)r.idx] = r.x;
-    xyz[3 * (size_t)r.idx + 1] = r.y;
-    xyz[3 * (size_t)r.idx + 2] = r.z;
-}
-
 template <typename T, typename REC>
 __global__ __launch_bounds__(256) void k_gather_records(const T *__restrict__ xyz, const uint32_t *__restrict__ vals,
                                                          int64_t n, REC *__restrict__ rec,
@@ -362,6 +351,35 @@ __global__ __launch_bounds__(256) void k_gather_records(const T *__restrict__ xy
     r.idx = (decltype(r.idx))j;
     rec[i] = r;
     if (perm) perm[i] = (int32_t)j;
+}
+
+// The same two steps from another level's records instead of the caller's array: a level of twice (or half)
+// the cell edge visits that level's records nearly in order, where the caller's array is visited at random.
+template <typename REC>
+__global__ __launch_bounds__(256) void k_cell_keys32_rec(const REC *__restrict__ src, int64_t n, GridParams gp,
+                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const REC r = src[i];
+    const double p[3] = {(double)r.x, (double)r.y, (double)r.z};
+    uint32_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double t = floor((p[a] - gp.o[a]) * gp.s);
+        c[a] = !(t > 0.0) ? 0u : (t >= (double)gp.dim[a] ? (uint32_t)(gp.dim[a] - 1) : (uint32_t)t);
+    }
+    keys[i] = (c[2] * (uint32_t)gp.dim[1] + c[1]) * (uint32_t)gp.dim[0] + c[0];
+    vals[i] = (uint32_t)i;
+}
+
+template <typename REC>
+__global__ __launch_bounds__(256) void k_regather_records(const REC *__restrict__ src, const uint32_t *__restrict__ vals,
+                                                           int64_t n, REC *__restrict__ rec, int32_t *__restrict__ perm) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const REC r = src[vals[i]];
+    rec[i] = r;
+    if (perm) perm[i] = (int32_t)r.idx;
 }
 
 __global__ __launch_bounds__(256) void k_segment_heads(const uint64_t *__restrict__ keys, int64_t n,
@@ -591,12 +609,11 @@ int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const doubl
     return PC_OK;
 }
 
-int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double cell_size, int k_hint, pc_grid **out,
-                  void *stream) {
-    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
-    if (!ctx || !out || n < 0 || n >= INT32_MAX || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
-        return pc_fail(ctx, PC_BAD_ARG, "pc_grid_build");
-    PC_HIP(hipSetDevice(ctx->device));
+// The index of a cloud given as an array (parent == NULL), or of the cloud another level of the same index
+// holds (parent: its records are the source, xyz_dev is not read; ties inside a cell then follow the parent's
+// order instead of the original index, which no search result depends on).
+static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double cell_size, int k_hint,
+                           pc_grid **out, void *stream, const pc_grid *parent) {
     hipStream_t st = (hipStream_t)stream;
     *out = nullptr;
     pc_grid *g = new (std::nothrow) pc_grid();
@@ -604,10 +621,22 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
     g->n = n;
     g->dtype = dtype;
     double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-    int rc = bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st);
+    int rc = PC_OK;
+    if (parent) {
+        for (int a = 0; a < 3; a++) {
+            mn[a] = parent->bb_min[a];
+            mx[a] = parent->bb_max[a];
+        }
+    } else {
+        rc = bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st);
+    }
     if (rc) {
         delete g;
         return rc;
+    }
+    for (int a = 0; a < 3; a++) {
+        g->bb_min[a] = mn[a];
+        g->bb_max[a] = mx[a];
     }
     double ext[3], emax = 0;
     for (int a = 0; a < 3; a++) {
@@ -670,7 +699,13 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             g->gp.cell = cell;
             g->gp.s = 1.0 / cell;
             g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
-            if (dtype == PC_F32)
+            if (parent && dtype == PC_F32)
+                hipLaunchKernelGGL(k_cell_keys32_rec<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                   (const Rec32 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+            else if (parent)
+                hipLaunchKernelGGL(k_cell_keys32_rec<Rec64>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                   (const Rec64 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+            else if (dtype == PC_F32)
                 hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
                                    (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
             else
@@ -780,7 +815,13 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
             }
         }
         const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
-        if (dtype == PC_F32)
+        if (parent && dtype == PC_F32)
+            hipLaunchKernelGGL(k_regather_records<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const Rec32 *)parent->rec, sv, n, (Rec32 *)g->rec, g->perm);
+        else if (parent)
+            hipLaunchKernelGGL(k_regather_records<Rec64>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                               (const Rec64 *)parent->rec, sv, n, (Rec64 *)g->rec, g->perm);
+        else if (dtype == PC_F32)
             hipLaunchKernelGGL((k_gather_records<float, Rec32>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
                                (const float *)xyz_dev, sv, n, (Rec32 *)g->rec, g->perm);
         else
@@ -806,7 +847,7 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
         for (int lv = 1; lv < MAX_LEVELS; lv++) {
             if (std::max(fine->gp.dim[0], std::max(fine->gp.dim[1], fine->gp.dim[2])) <= 4) break;
             pc_grid *c = nullptr;
-            rc = pc_grid_build(ctx, xyz_dev, dtype, n, fine->gp.cell * 2.0, k_hint, &c, stream);
+            rc = grid_build_impl(ctx, nullptr, dtype, n, fine->gp.cell * 2.0, k_hint, &c, stream, fine);
             if (rc) {
                 pc_grid_destroy(ctx, g);
                 return rc;
@@ -822,25 +863,23 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
     return PC_OK;
 }
 
+int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double cell_size, int k_hint, pc_grid **out,
+                  void *stream) {
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    if (!ctx || !out || n < 0 || n >= INT32_MAX || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_grid_build");
+    PC_HIP(hipSetDevice(ctx->device));
+    return grid_build_impl(ctx, xyz_dev, dtype, n, cell_size, k_hint, out, stream, nullptr);
+}
+
 }  // extern "C"
 
 int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out) {
     *out = g->finer;
     if (g->finer || g->finer_tried || g->n <= 0) return PC_OK;
     g->finer_tried = true;
-    // the builder wants the cloud as an array: put the records' coordinates back at their indices
-    const size_t esz = g->dtype == PC_F32 ? sizeof(float) : sizeof(double);
-    Scratch xyz(ctx, 3 * esz * (size_t)g->n);
-    if (!xyz.ok()) return pc_fail(ctx, PC_NOMEM, "finer grid");
-    if (g->dtype == PC_F32)
-        hipLaunchKernelGGL((k_scatter_coords<float, Rec32>), dim3(blocks_for(g->n, 256)), dim3(256), 0, st,
-                           (const Rec32 *)g->rec, g->n, xyz.as<float>());
-    else
-        hipLaunchKernelGGL((k_scatter_coords<double, Rec64>), dim3(blocks_for(g->n, 256)), dim3(256), 0, st,
-                           (const Rec64 *)g->rec, g->n, xyz.as<double>());
-    PC_HIP(hipGetLastError());
     pc_grid *f = nullptr;
-    PC_TRY(pc_grid_build(ctx, xyz.p, g->dtype, g->n, 0.5 * g->gp.cell, 0, &f, (void *)st));
+    PC_TRY(grid_build_impl(ctx, nullptr, g->dtype, g->n, 0.5 * g->gp.cell, 0, &f, (void *)st, g));
     if (f->gp.cell > 0.93 * g->gp.cell) {  // the cell-key range binds: no finer grid
         pc_grid_destroy(ctx, f);
         return PC_OK;
