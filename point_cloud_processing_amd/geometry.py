@@ -254,6 +254,7 @@ class PointCloud:
         if self._normals is None or n == 0:
             raise RuntimeError("[Open3D Error] No normals in the PointCloud. Call EstimateNormals() first.")
         kk = max(2, min(int(k), n, 64))
+        kk = max(2, min(kk, (2 ** 32 - 1) // n))  # (the engine numbers the neighbour slots in 32 bits)
         self._normals, _ = _engine.get().orient_normals(self._points, self._normals, kk, self._cache)
 
     def remove_statistical_outlier(self, nb_neighbors: int, std_ratio: float, print_progress: bool = False):
