@@ -134,8 +134,12 @@ struct pc_grid {
     int32_t *perm = nullptr;      // sorted position -> original index
     int64_t ncell = 0;
     size_t bytes = 0;
-    int64_t occupied = 0;     // number of non-empty cells (0: not measured)
-    double seen = 0.0;        // points in the cell of a random point (point-weighted occupancy)
+    mutable int64_t occupied = 0;     // number of non-empty cells (0: not measured)
+    mutable double seen = 0.0;        // points in the cell of a random point (point-weighted occupancy)
+    // levels built from another level leave the two sums behind those numbers on the device and are read
+    // on first need (pc_grid_stats): one host round trip less per level
+    mutable unsigned long long *stats_dev = nullptr;
+    mutable bool stats_pending = false;
     // tile shape of the cooperative kNN kernel, chosen on first use (0: not chosen yet)
     mutable int tile[3] = {0, 0, 0};
     mutable int tile_cap = 0;
@@ -160,6 +164,8 @@ struct pc_grid {
 };
 
 // pc_grid.hip
+// fills g->occupied / g->seen if they are still on the device (synchronises then)
+int pc_grid_stats(pc_ctx *ctx, const pc_grid *g, hipStream_t st);
 // the same cloud on cells of half the edge (cached in g->finer); *out = NULL if the key range forbids it
 int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out);
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,

@@ -736,13 +736,28 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                 hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
             }
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
-            if (hipMemsetAsync(stats.p, 0, 2 * 8, st) != hipSuccess) break;
+            // (a level made from another level has its cell edge given: nothing here waits for the numbers)
+            const bool defer = parent != nullptr && !automatic;
+            unsigned long long *sdev = stats.as<unsigned long long>();
+            if (defer) {
+                g->stats_dev = (unsigned long long *)ctx->alloc(256);
+                if (!g->stats_dev) {
+                    rc = pc_fail(ctx, PC_NOMEM, "grid statistics");
+                    break;
+                }
+                sdev = g->stats_dev;
+            }
+            if (hipMemsetAsync(sdev, 0, 2 * 8, st) != hipSuccess) break;
             if (dense)
                 hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 512u)), dim3(256), 0, st,
-                                   g->cell_start, g->ncell, stats.as<unsigned long long>());
+                                   g->cell_start, g->ncell, sdev);
             else
                 hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st, sorted_keys,
-                                   n, stats.as<unsigned long long>());
+                                   n, sdev);
+            if (defer) {
+                g->stats_pending = true;
+                break;
+            }
             if (hipMemcpyAsync(hs, stats.p, 2 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) {
                 rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
@@ -827,7 +842,9 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         else
             hipLaunchKernelGGL((k_gather_records<double, Rec64>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
                                (const double *)xyz_dev, sv, n, (Rec64 *)g->rec, g->perm);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        // (the caller's array may change once this returns; a level made from another level reads only
+        // buffers the index owns and need not wait)
+        if (hipGetLastError() != hipSuccess || (!parent && hipStreamSynchronize(st) != hipSuccess))
             rc = pc_fail(ctx, PC_HIP_ERROR, "grid build kernels");
     } while (0);
     if (rc) {
@@ -873,6 +890,17 @@ int pc_grid_build(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double
 }
 
 }  // extern "C"
+
+int pc_grid_stats(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
+    if (!g->stats_pending) return PC_OK;
+    unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(hs, g->stats_dev, 2 * 8, hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    g->seen = g->n > 0 ? (double)hs[0] / (double)g->n : 0.0;
+    g->occupied = (int64_t)hs[1];
+    g->stats_pending = false;
+    return PC_OK;
+}
 
 int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out) {
     *out = g->finer;
@@ -935,6 +963,7 @@ void pc_grid_destroy(pc_ctx *ctx, pc_grid *g) {
         if (g->row_start) ctx->release(g->row_start);
         if (g->tile_list) ctx->release(g->tile_list);
         if (g->full_tiles) ctx->release(g->full_tiles);
+        if (g->stats_dev) ctx->release(g->stats_dev);
         if (g->perm) ctx->release(g->perm);
     }
     delete g;

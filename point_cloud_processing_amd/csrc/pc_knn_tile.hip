@@ -275,6 +275,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         if (!g->uneven || !g->tile_list || grow >= 3) break;
         // grow only where the occupied cells are evenly filled (a surface of even density): the mean
         // says nothing about a cloud whose points sit mostly in a few full tiles among many empty ones
+        PC_TRY(pc_grid_stats(ctx, g, st));
         const double pop = (double)g->n / (double)std::max<int64_t>(1, g->tile_count);
         const double cell_mean = (double)g->n / (double)std::max<int64_t>(1, g->occupied);
         if (pop >= 16.0 || g->occupied <= 0 || g->seen > 2.0 * (cell_mean + 1.0)) break;
