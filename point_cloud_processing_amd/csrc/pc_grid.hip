@@ -214,9 +214,12 @@ __global__ __launch_bounds__(256) void k_cell_keys(const T *__restrict__ xyz, in
 }
 
 // kNN grid keys as u32 (the dense table has fewer than 2^32 cells)
+// (halfbit: one more key bit below the cell, set for points in the upper x-half of their cell -- the
+// expression x_half_of() in pc_common.h, which the tile kernel repeats)
 template <typename T>
 __global__ __launch_bounds__(256) void k_cell_keys32(const T *__restrict__ xyz, int64_t n, GridParams gp,
-                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                      int halfbit = 0) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     uint32_t c[3];
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(256) void k_cell_keys32(const T *__restrict__ xyz, 
         const double t = floor(((double)xyz[3 * i + a] - gp.o[a]) * gp.s);
         c[a] = !(t > 0.0) ? 0u : (t >= (double)gp.dim[a] ? (uint32_t)(gp.dim[a] - 1) : (uint32_t)t);
     }
-    keys[i] = (c[2] * (uint32_t)gp.dim[1] + c[1]) * (uint32_t)gp.dim[0] + c[0];
+    uint32_t key = (c[2] * (uint32_t)gp.dim[1] + c[1]) * (uint32_t)gp.dim[0] + c[0];
+    if (halfbit) key = (key << 1) | x_half_of((double)xyz[3 * i], gp, (int)c[0]);
+    keys[i] = key;
     vals[i] = (uint32_t)i;
 }
 
@@ -233,12 +238,12 @@ __global__ __launch_bounds__(256) void k_cell_keys32(const T *__restrict__ xyz, 
 // position, the first subtracts its start position (u32 wrap-around cancels); two contention-free
 // atomics per occupied cell.  cnt must be zero on entry.
 __global__ __launch_bounds__(256) void k_cell_runs(const uint32_t *__restrict__ keys, int64_t n,
-                                                    uint32_t *__restrict__ cnt) {
+                                                    uint32_t *__restrict__ cnt, int shift = 0) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t key = keys[i];
-    const bool head = i == 0 || keys[i - 1] != key;
-    const bool tail = i + 1 == n || keys[i + 1] != key;
+    const uint32_t key = keys[i] >> shift;  // (the cell, without the x-half bit)
+    const bool head = i == 0 || (keys[i - 1] >> shift) != key;
+    const bool tail = i + 1 == n || (keys[i + 1] >> shift) != key;
     if (head && tail)
         cnt[key] = 1u;
     else if (tail)
@@ -699,6 +704,11 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             g->gp.cell = cell;
             g->gp.s = 1.0 / cell;
             g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
+            // evenly filled fp32 clouds (decided later; the bit is harmless otherwise): x-halves inside the cells
+            dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
+            const int halfbit = (!parent && automatic && dense && dtype == PC_F32 && g->ncell < (1ll << 31) &&
+                                 !getenv("PC_AMD_NO_HALVES")) ? 1 : 0;
+            g->halves = halfbit != 0;
             if (parent && dtype == PC_F32)
                 hipLaunchKernelGGL(k_cell_keys32_rec<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
                                    (const Rec32 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
@@ -707,12 +717,12 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                                    (const Rec64 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
             else if (dtype == PC_F32)
                 hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                                   (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+                                   (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), halfbit);
             else
                 hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                                   (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+                                   (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), 0);
             rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
-                                       vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1), st, &in_tmp);
+                                       vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1) + halfbit, st, &in_tmp);
             if (rc) break;
             const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
             // per-cell counts (the offset table before its scan) while the table stays within 8 n + 4096
@@ -733,7 +743,8 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                     rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell table");
                     break;
                 }
-                hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start);
+                hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start,
+                                   halfbit);
             }
             unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
             // (a level made from another level has its cell edge given: nothing here waits for the numbers)

@@ -78,6 +78,7 @@ struct ScanArgs {
     int32_t *flag2_list;    // queries the wave-per-query re-run hands on to the per-lane scan
     uint32_t *flag2_count;
     uint32_t flag_cap;
+    int halves;             // the records of a cell are ordered low x-half first (fp32 grids of evenly filled clouds)
     int count_crowded;      // this pass counts the queries amid more candidates than a tile stages (flag_count[26])
     // wave-per-query re-run: the index levels, finest first
     Level lv[MAX_LEVELS];

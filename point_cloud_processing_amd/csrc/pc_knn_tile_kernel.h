@@ -113,7 +113,8 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     // one area of lane-private columns: parked keys during the filter, result order afterwards
     const int tid = threadIdx.x, lane = tid & (PC_WAVE - 1), wid = tid >> 6, nthr = blockDim.x;
     // (one such area per wave)
-    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_off + MAX_ROWS * (MAX_NX + 1)) +
+    uint16_t *cell_mid = cell_off + MAX_ROWS * (MAX_NX + 1);                                       // [64][MAX_NX+1]
+    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_mid + MAX_ROWS * (MAX_NX + 1)) +
                        wid * max(PC_WAVE * (SEL_SLOTS + 1), (PC_WAVE / 2) * A.k);           // [SEL_SLOTS + 1][64]
     uint16_t *ordbuf = reinterpret_cast<uint16_t *>(selbuf);                                       // [k][64]
     const GridParams &gp = A.gp;
@@ -122,6 +123,10 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     const REC *qsrc = A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec;
     const CellIndex &qix = A.qrec ? A.qci : A.ci;
     const int k = A.k;
+    // Records of a cell ordered low x-half first: a query in the low half of its cell leaves out the high half
+    // of the cell after it, one in the high half the low half of the cell before it -- 2.5 cells per row
+    // instead of 3, and the scanned region still reaches a full cell edge beyond the query on either side.
+    const bool halves = !UNEVEN && !TileRec<REC>::kRelative && A.halves;
 
     int c1[3], lo[3], hi[3];                                              // last cell; block bounds
 #pragma unroll
@@ -247,6 +252,22 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         cell_off[r * (MAX_NX + 1) + i] = (uint16_t)(row_off[r] + (cell_begin(A.ci, row + lo[0] + i) - row_src[r]));
     }
     __syncthreads();
+    if (halves) {
+        // first high-half record of every block cell (the records of a cell are ordered by that bit)
+        for (int e = tid; e < nrows * nx; e += nthr) {
+            const int r = e / nx, i = e - r * nx;
+            int a = cell_off[r * (MAX_NX + 1) + i], b = cell_off[r * (MAX_NX + 1) + i + 1];
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if (x_half_of((double)cxyz[3 * m], gp, lo[0] + i))
+                    b = m;
+                else
+                    a = m + 1;
+            }
+            cell_mid[r * (MAX_NX + 1) + i] = (uint16_t)a;
+        }
+        __syncthreads();
+    }
 
     const double eps = 1e-7 * gp.cell;
     const double r2lim = A.radius2;
@@ -335,6 +356,14 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
         }
         const int i0 = max(qc[0] - 1, 0) - lo[0], i1 = min(qc[0] + 1, gp.dim[0] - 1) - lo[0] + 1;
+        // which half-cell the walk leaves out: +1 the high half of the cell after the query's, -1 the low
+        // half of the cell before it, 0 nothing (no such cell, or no halves in this grid)
+        int trim = 0;
+        if (halves) {
+            const uint32_t hq = x_half_of(qxd, gp, qc[0]);
+            if (!hq && qc[0] + 1 <= gp.dim[0] - 1) trim = 1;
+            if (hq && qc[0] - 1 >= 0) trim = -1;
+        }
         // the nine (start, length) pairs and the wave-wide longest length of each, up front:
         // the nine max-reductions overlap instead of serialising in front of every segment.
         // Order: the query's own row, the four rows sharing a face with it, the four diagonal ones,
@@ -349,8 +378,8 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             uint32_t st = 0, ln = 0;
             if (live && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2]) {
                 const int r = (y - lo[1]) + nry * (z - lo[2]);
-                st = cell_off[r * (MAX_NX + 1) + i0];
-                ln = cell_off[r * (MAX_NX + 1) + i1] - st;
+                st = trim < 0 ? cell_mid[r * (MAX_NX + 1) + i0] : cell_off[r * (MAX_NX + 1) + i0];
+                ln = (trim > 0 ? cell_mid[r * (MAX_NX + 1) + i1 - 1] : cell_off[r * (MAX_NX + 1) + i1]) - st;
             }
             seg_pack[seg] = st | (ln << 16);
             seg_max[seg] = (int)ln;
@@ -434,6 +463,11 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             if (nhi < gp.dim[a] - 1) {
                 whole = false;
                 dmin = fmin(dmin, (gp.o[a] + (double)(nhi + 1) * gp.cell) - qv[a]);
+            }
+            if (a == 0 && trim != 0) {  // the half-cell left out begins in the middle of its cell
+                whole = false;
+                const double mid = gp.o[0] + ((double)(qc[0] + trim) + 0.5) * gp.cell;
+                dmin = fmin(dmin, trim > 0 ? mid - qv[0] : qv[0] - mid);
             }
         }
         double bound = INFINITY;  // no unscanned point is closer than sqrt(bound)
