@@ -706,7 +706,8 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
             // evenly filled fp32 clouds (decided later; the bit is harmless otherwise): x-halves inside the cells
             dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
-            const int halfbit = (!parent && automatic && dense && dtype == PC_F32 && g->ncell < (1ll << 31) &&
+            // (not for the nearly empty cells of k <= 2: nothing to gain from halving one or two points)
+            const int halfbit = (!parent && automatic && dense && dtype == PC_F32 && g->ncell < (1ll << 31) && k_hint > 2 &&
                                  !getenv("PC_AMD_NO_HALVES")) ? 1 : 0;
             g->halves = halfbit != 0;
             if (parent && dtype == PC_F32)
