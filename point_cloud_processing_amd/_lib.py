@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpc_amd.so")
+LIB_PATH = os.environ.get("PC_AMD_LIB") or os.path.join(_HERE, "libpc_amd.so")  # (override: A/B runs of two builds)
 
 PC_F32, PC_F64 = 0, 1
 PC_MAX_K = 64

@@ -114,7 +114,8 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     const int tid = threadIdx.x, lane = tid & (PC_WAVE - 1), wid = tid >> 6, nthr = blockDim.x;
     // (one such area per wave)
     uint16_t *cell_mid = cell_off + MAX_ROWS * (MAX_NX + 1);                                       // [64][MAX_NX+1]
-    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_mid + MAX_ROWS * (MAX_NX + 1)) +
+    // (the table of mid points exists only where it is used: the launch sizes LDS the same way)
+    uint32_t *selbuf = reinterpret_cast<uint32_t *>(cell_mid + (A.halves ? MAX_ROWS * (MAX_NX + 1) : 0)) +
                        wid * max(PC_WAVE * (SEL_SLOTS + 1), (PC_WAVE / 2) * A.k);           // [SEL_SLOTS + 1][64]
     uint16_t *ordbuf = reinterpret_cast<uint16_t *>(selbuf);                                       // [k][64]
     const GridParams &gp = A.gp;
