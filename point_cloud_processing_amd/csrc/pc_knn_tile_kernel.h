@@ -678,8 +678,12 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     return 0;
 }
 
+// Four waves per SIMD for the short lists whatever the consumer (plain rows fit anyway): the eigen-solver of the
+// normals peaks above 128 registers once per query, far from the filter loop that sets the pace, and may spill
+// there (fused pipeline on 10 M points: 4.28 -> 3.97 ms).
 template <typename REC, int KS, int MODE, bool SPLIT>
-__global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) void k_tile_scan(ScanArgs A) {
+__global__ __launch_bounds__(PC_WAVE * MAX_TILE_WAVES) __attribute__((amdgpu_waves_per_eu(KS <= 18 && MODE != M_KNN ? 4 : 1)))
+void k_tile_scan(ScanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // tile coordinates (x fastest so that neighbouring blocks share L2 lines)
     // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  Remap so
