@@ -133,6 +133,12 @@ int build_tile_list_dense(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
     return PC_OK;
 }
 
+// candidates an uneven level's tile stages (tuning knob: PC_AMD_UNEVEN_CAP)
+int uneven_cap() {
+    if (const char *e = getenv("PC_AMD_UNEVEN_CAP")) return std::min(CAND_CAP_MAX, std::max(256, atoi(e) / 64 * 64));
+    return UNEVEN_CAP;
+}
+
 // flags[i] = listed tile i holds at least `thresh` points; *points += the points of those tiles
 __global__ __launch_bounds__(256) void k_tile_full(GridParams gp, CellIndex ci, int tx, int ty, int tz, int ntx, int nty,
                                                     const uint32_t *__restrict__ tiles, int64_t m, uint32_t thresh,
@@ -260,7 +266,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         int base = g->level > 0 ? 1 : 2;
         if (const char *e = getenv(g->level > 0 ? "PC_AMD_UNEVEN_TILE1" : "PC_AMD_UNEVEN_TILE0")) base = std::max(1, atoi(e));
         for (int a = 0; a < 3; a++) best[a] = std::min(std::min(base, a == 0 ? MAX_NX - 2 : 6), std::max(1, (int)g->gp.dim[a]));
-        expect = UNEVEN_CAP;
+        expect = uneven_cap();
         waves = 1;  // (passes over few tiles take two: uneven_waves below)
     }
     int cap = ((int)expect + 63) / 64 * 64;
@@ -572,7 +578,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.gp = fine->gp;
             A.rec = fine->rec;
             A.ci = fine->index();
-            A.cand_cap = UNEVEN_CAP;
+            A.cand_cap = uneven_cap();
             A.qflag_in = qflag;
             A.qflag_out = qflag;
             int64_t nopen = 0, open = 0;
