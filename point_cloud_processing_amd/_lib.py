@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("PC_AMD_LIB") or os.path.join(_HERE, "libpc_amd.so")  
 
 PC_F32, PC_F64 = 0, 1
 PC_MAX_K = 64
+PC_SOR_SELECT_STATIC_MAX_N = 4 * 1024 * 1024
 
 # every symbol include/pc_amd.h declares: (name, restype, argtypes)
 _vp, _i64, _i32, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
@@ -40,6 +41,7 @@ SYMBOLS = [
     ("pc_sor_sum", _i32, [_vp, _vp, _i64, _pd, _pi64, _vp]),
     ("pc_sor_sqsum", _i32, [_vp, _vp, _i64, _dbl, _pd, _vp]),
     ("pc_sor_select", _i32, [_vp, _vp, _i64, _dbl, _vp, _vp, _pi64, _vp]),
+    ("pc_sor_select_static", _i32, [_vp, _vp, _i64, _dbl, _vp, _vp, _pi64, _vp]),
     ("pc_normals", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _vp]),
     ("pc_radius_count", _i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _dbl, _vp, _vp]),
     ("pc_nn_distance", _i32, [_vp, _vp, _i64, _i64, _vp, _vp]),

@@ -182,6 +182,8 @@ int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq,
                    hipStream_t st);
 
 // pc_sort.hip
+// device address of this GPU's copy of the static scratch array behind pc_sor_select_static (once per device)
+int pc_static_scratch_init(int device);
 int pc_radix_sort_pairs(pc_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
                         int64_t n, int key_bits, hipStream_t st, bool *result_in_tmp);
 int pc_radix_sort_pairs32(pc_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,

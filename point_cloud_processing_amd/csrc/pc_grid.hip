@@ -87,6 +87,11 @@ int pc_create(int device, pc_ctx **out) {
         delete c;
         return PC_NOMEM;
     }
+    if (pc_static_scratch_init(device) != PC_OK) {
+        (void)hipHostFree(c->pinned);
+        delete c;
+        return PC_HIP_ERROR;
+    }
     *out = c;
     return PC_OK;
 }

@@ -323,3 +323,80 @@ int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_
     *count = (int64_t)*total;
     return PC_OK;
 }
+
+// ---- pc_sor_select_static: the ordered select of the statistical filter without any allocation ---------
+// Same kernels as pc_sor_select / pc_compact_flags; the flag bytes and the per-block counts live in a
+// file-scope device array instead of pooled blocks.  Every GPU holds its own copy of the array (at its own
+// address, looked up once per device in pc_static_scratch_init) until the process ends.  Calls share it:
+// two calls that overlap on one GPU race.
+namespace {
+
+constexpr int64_t STATIC_MAX_N = PC_SOR_SELECT_STATIC_MAX_N;
+constexpr size_t STATIC_COUNT_BLOCKS = (size_t)(STATIC_MAX_N / CMP_TILE) + 1;         // + the total
+constexpr size_t STATIC_COUNT_BYTES = (STATIC_COUNT_BLOCKS * sizeof(uint32_t) + 255) & ~size_t(255);
+constexpr size_t STATIC_BYTES = (size_t)STATIC_MAX_N + STATIC_COUNT_BYTES;  // flag bytes, then the counts
+static_assert(STATIC_COUNT_BLOCKS <= (size_t)SCAN_TILE, "the block counts must fit one scan block");
+
+static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
+
+constexpr int STATIC_MAX_DEVICES = 64;
+void *g_scratch_ptr[STATIC_MAX_DEVICES];  // device address of `scratch` on each GPU (NULL: not looked up)
+std::mutex g_scratch_mu;
+
+__global__ __launch_bounds__(256) void k_threshold_flags(const double *__restrict__ avg, int64_t n, double thr,
+                                                          uint8_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const double v = avg[i];
+        flags[i] = (v > 0 && v < thr) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+// Called by pc_create with `device` current: the address of this GPU's copy of the scratch array.
+int pc_static_scratch_init(int device) {
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return PC_OK;  // (pc_sor_select_static reports it)
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return PC_OK;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PC_HIP_ERROR;
+    g_scratch_ptr[device] = p;
+    return PC_OK;
+}
+
+extern "C" int pc_sor_select_static(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshold,
+                                    uint8_t *out_mask_dev, int32_t *out_kept_dev, int64_t *n_kept, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || n < 0 || (n > 0 && !avg_dev) || !n_kept) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_select_static");
+    if (n > STATIC_MAX_N)
+        return pc_fail(ctx, PC_BAD_ARG, "pc_sor_select_static: more than PC_SOR_SELECT_STATIC_MAX_N values");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *n_kept = 0;
+    if (n == 0) return PC_OK;
+    unsigned char *base = nullptr;
+    if (ctx->device >= 0 && ctx->device < STATIC_MAX_DEVICES) {
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        base = reinterpret_cast<unsigned char *>(g_scratch_ptr[ctx->device]);
+    }
+    if (!base) return pc_fail(ctx, PC_HIP_ERROR, "pc_sor_select_static: no static scratch on this device");
+    uint8_t *flags = out_mask_dev ? out_mask_dev : base;
+    uint32_t *c = reinterpret_cast<uint32_t *>(base + STATIC_MAX_N);
+    const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
+    // the slot behind the block counts becomes the total and must start at zero (the array keeps the
+    // previous call's contents)
+    PC_HIP(hipMemsetAsync(c + nb, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_threshold_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, avg_dev, n, threshold,
+                       flags);
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c);
+    hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(SCAN_THREADS), 0, st, c, nb + 1, (const uint32_t *)nullptr);
+    if (out_kept_dev)
+        hipLaunchKernelGGL(k_compact_write, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c, out_kept_dev);
+    PC_HIP(hipGetLastError());
+    uint32_t *total = reinterpret_cast<uint32_t *>(ctx->pinned);  // page-locked since pc_create
+    PC_HIP(hipMemcpyAsync(total, c + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    *n_kept = (int64_t)*total;
+    return PC_OK;
+}
