@@ -186,8 +186,9 @@ int launch_scan(pc_ctx *ctx, const pc_grid *g, int qdtype, const ScanArgs &A0, h
         fprintf(stderr, "[pc_amd] n=%lld k=%d tile=%dx%dx%d cap=%d tiles=%lld: wave-per-query %u, per-lane %u\n",
                 (long long)A.nq, A.k, A.tile[0], A.tile[1], A.tile[2], A.cand_cap,
                 (long long)(g->tile_list ? g->tile_count : (int64_t)A.ntile[0] * A.ntile[1] * A.ntile[2]), c[0], c[16]);
-        if (c[24] | c[25])  // only counted by builds with -DPC_COUNT
-            fprintf(stderr, "[pc_amd]   filter steps (pairs, per wave) %u, insertion steps %u\n", c[24], c[25]);
+        if (c[28])  // only counted by builds with -DPC_COUNT
+            fprintf(stderr, "[pc_amd]   per 64-query batch (%u batches): filter steps %.1f, insertion rounds %.1f, drains %.2f\n", c[28],
+                    (double)c[24] / c[28], (double)c[25] / c[28], (double)c[27] / c[28]);
     }
     return PC_OK;
 }

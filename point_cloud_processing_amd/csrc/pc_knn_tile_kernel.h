@@ -10,6 +10,8 @@ constexpr int ORD_BITS = 11;
 constexpr int CAND_CAP_MAX = 1 << ORD_BITS;  // most candidates one tile may stage (32 KiB of LDS)
 constexpr uint32_t ORD_MASK = CAND_CAP_MAX - 1;
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t KEY_INF = 0x7F800000u;  // key of an infinite distance: such keys (sentinels, overflowed sums) never enter a list
+constexpr uint32_t DRAIN_ROUNDS = 8;      // parked keys one lane inserts per drain while the scan is running
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float lds_f32;    // 32-bit LDS addresses: no 64-bit pointer math
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -38,6 +40,8 @@ __device__ inline uint32_t lds_read_u32(uint32_t addr) {
     return v;
 }
 __device__ inline void lds_write_u32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v)); }
+// (the slot one row of the wave's area above `addr`)
+__device__ inline void lds_write_u32_next(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1 offset:256" : : "v"(addr), "v"(v)); }
 __device__ inline void lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
 
 // Maximum over the wave (uniform result): butterfly inside each row of 16 lanes with DPP
@@ -49,6 +53,65 @@ __device__ inline int wave_max_i32(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// The filter's inner loop over one row segment, for the whole wave: lanes with j0 < end measure the candidate
+// pair (j0, j0 + 1) against their query in packed fp32, build the keys and push them on their stack of
+// parked keys (always written to the slot above the stack, which then grows by one slot or not: no
+// branch), until every lane is through its segment or some lane's stack has reached wp_full.  nx/ny/nz
+// hold the pair requested last (the request for the next pair goes out as soon as this one is consumed).
+// Written as one block because the compiler's version of the same loop spends a third of its instructions
+// on exec-mask bookkeeping.  Waits that gfx950 wants between dependent instructions are met by the order:
+// a packed-fp32 result is read two instructions later at the earliest, a compare's mask three later.
+__device__ inline void scan_pairs(uint32_t &j0, const uint32_t end, uint32_t &pa, uint32_t &wp, f32x2 &nx, f32x2 &ny,
+                                  f32x2 &nz, const f32x2 qx, const f32x2 qy, const f32x2 qz, const uint32_t thr,
+                                  const uint32_t wp_full) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (gfx950 text: nothing for the host pass to parse)
+    const uint32_t keep = ~ORD_MASK, inc = 4u * PC_WAVE;
+    uint64_t saved, m0;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "v_cmpx_lt_u32 %[j0], %[end]\n\t"
+        "s_cbranch_execz 2f\n"
+        "1:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_add_f32 v[120:121], %[qx], %[nx] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[122:123], %[qy], %[ny] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[124:125], %[qz], %[nz] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_add_u32 %[pa], 24, %[pa]\n\t"
+        "v_pk_mul_f32 v[120:121], v[120:121], v[120:121]\n\t"
+        "ds_read2_b32 %[nx], %[pa] offset1:3\n\t"
+        "ds_read2_b32 %[ny], %[pa] offset0:1 offset1:4\n\t"
+        "ds_read2_b32 %[nz], %[pa] offset0:2 offset1:5\n\t"
+        "s_nop 0\n\t"
+        "v_pk_fma_f32 v[120:121], v[122:123], v[122:123], v[120:121]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_fma_f32 v[120:121], v[124:125], v[124:125], v[120:121]\n\t"
+        "s_nop 0\n\t"
+        "v_and_or_b32 v126, v120, %[keep], %[j0]\n\t"
+        "v_and_or_b32 v127, v121, %[keep], %[j0]\n\t"
+        "v_add_u32 v127, 1, v127\n\t"
+        "v_cmp_lt_u32 %[m0], v126, %[thr]\n\t"
+        "ds_write_b32 %[wp], v126 offset:256\n\t"
+        "v_cmp_lt_u32 vcc, v127, %[thr]\n\t"
+        "v_add_u32 %[j0], 2, %[j0]\n\t"
+        "v_cndmask_b32 v126, 0, %[inc], %[m0]\n\t"
+        "v_add_u32 %[wp], %[wp], v126\n\t"
+        "v_cndmask_b32 v126, 0, %[inc], vcc\n\t"
+        "ds_write_b32 %[wp], v127 offset:256\n\t"
+        "v_add_u32 %[wp], %[wp], v126\n\t"
+        "v_cmp_ge_u32 vcc, %[wp], %[full]\n\t"
+        "s_cbranch_vccnz 2f\n\t"
+        "v_cmpx_lt_u32 %[j0], %[end]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [j0] "+v"(j0), [pa] "+v"(pa), [wp] "+v"(wp), [nx] "+v"(nx), [ny] "+v"(ny), [nz] "+v"(nz), [saved] "=&s"(saved),
+          [m0] "=&s"(m0)
+        : [end] "v"(end), [qx] "v"(qx), [qy] "v"(qy), [qz] "v"(qz), [thr] "v"(thr), [full] "v"(wp_full), [keep] "s"(keep),
+          [inc] "v"(inc)
+        : "vcc", "scc", "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+#endif
 }
 
 template <int KS>
@@ -244,6 +307,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
         }
     }
+    // Two sentinel candidates behind the block, infinitely far away: the filter reads candidates in pairs and may
+    // read one past the end of a row segment (see stage 1).
+    if (!overfull && tid < 6) cxyz[3 * ncand + tid] = 1e30f;
     // block-relative offset of every cell boundary of every block row
     const int nx = hi[0] - lo[0] + 1;
     for (int e = tid; e < nrows * (nx + 1); e += nthr) {
@@ -320,32 +386,46 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
 
         // ---- stage 1: fp32 filter over the lane's own 3x3x3 cells --------------------------------
         // Lanes of one cell walk the same LDS range (broadcast reads); the nine (dy, dz) row
-        // segments are visited in lock-step, each for the longest segment any lane has.
+        // segments are visited one after the other, each until the wave's longest segment is done
+        // (lanes with shorter ones sit out the rest of that loop).
         // A key can enter the list only if it is below the list's current last entry.  The lane
-        // keeps a copy `thr` of that entry and parks the keys below it in its own column of selbuf;
-        // the (expensive) sorted insertion runs over the parked keys only, when some lane's column
-        // is nearly full and once more at the end.  `thr` lags behind the list, which only lets a
-        // few keys too many through: the final list is the same KS smallest keys either way.
-        uint32_t thr = KEY_EMPTY;
+        // keeps a copy `thr` of that entry and parks the keys below it on a stack in its own column of
+        // selbuf; the (expensive) sorted insertion runs over parked keys only.  When some lane's stack is
+        // nearly full every lane inserts its newest DRAIN_ROUNDS keys and keeps the rest parked: the wave
+        // then pays for about the mean stack, not for the fullest one (rounds per 64 queries 89 -> 69 in
+        // a model of the uniform 10 M cloud); what is left is inserted at the end.  `thr` lags behind
+        // the list, which only lets a few keys too many through: the final list is the same KS
+        // smallest keys either way.
+        uint32_t thr = KEY_INF;
+#ifdef PC_COUNT
+        uint32_t n_steps = 0, n_rounds = 0, n_drains = 0, n_lock = 0;
+#endif
         lds_u32 *const col = (lds_u32 *)selbuf + lane;  // slot s of this lane: col[s * 64]
         const uint32_t col_a = (uint32_t)(uintptr_t)col;                   // LDS byte address of the column
         uint32_t wp = col_a - 4u * PC_WAVE;                                // last written slot (byte address)
-        auto drain = [&]() {
-            const uint32_t have = (wp + 4u * PC_WAVE - col_a) >> 8;
-            uint32_t ra = (uint32_t)(uintptr_t)col;
-            uint32_t nxt = lds_read_u32(ra);
-            uint32_t s = 0;
+        auto drain = [&](const uint32_t rounds) {  // (rounds: the same for all lanes)
+            uint32_t ra = wp;
+            uint32_t nxt = lds_read_u32(ra);  // (an empty stack reads the row in front of its column: not used)
+            bool valid = ra >= col_a;
+            uint32_t r = 0;
             do {  // at least one round: a round of empty keys changes nothing
                 lds_wait(nxt);
-                const uint32_t key = s < have ? nxt : KEY_EMPTY;
-                ra += 4 * PC_WAVE;
-                nxt = lds_read_u32(ra);  // one slot ahead (the area has a spare row)
+                const uint32_t key = valid ? nxt : KEY_EMPTY;
+                ra -= 4u * PC_WAVE;
+                nxt = lds_read_u32(ra);  // one slot ahead
                 list_insert<KS>(L, key);
-                s++;
-            } while (__any(s < have));
+                valid = ra >= col_a;
+                r++;
+#ifdef PC_COUNT
+                n_rounds++;
+#endif
+            } while (r < rounds && __any(valid));
             lds_wait(nxt);
-            thr = L[KS - 1];
-            wp = col_a - 4u * PC_WAVE;
+#ifdef PC_COUNT
+            n_drains++;
+#endif
+            wp = valid ? ra : col_a - 4u * PC_WAVE;
+            thr = min(L[KS - 1], KEY_INF);
         };
         int qc[3];
         {
@@ -365,14 +445,12 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             if (!hq && qc[0] + 1 <= gp.dim[0] - 1) trim = 1;
             if (hq && qc[0] - 1 >= 0) trim = -1;
         }
-        // the nine (start, length) pairs and the wave-wide longest length of each, up front:
-        // the nine max-reductions overlap instead of serialising in front of every segment.
+        // the nine (start, length) pairs up front.
         // Order: the query's own row, the four rows sharing a face with it, the four diagonal ones,
         // so that the threshold tightens early.
         constexpr int SEG_DY[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
         constexpr int SEG_DZ[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
         uint32_t seg_pack[9];  // start | len << 16
-        int seg_max[9];
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
             const int y = qc[1] + SEG_DY[seg], z = qc[2] + SEG_DZ[seg];
@@ -383,7 +461,6 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 ln = (trim > 0 ? cell_mid[r * (MAX_NX + 1) + i1 - 1] : cell_off[r * (MAX_NX + 1) + i1]) - st;
             }
             seg_pack[seg] = st | (ln << 16);
-            seg_max[seg] = (int)ln;
         }
         // A query with fewer than 2 k candidates in its 27 cells will not find k of them inside the reach of
         // those cells (a ball inscribed in the block holds a fifth of an evenly filled block's points, under
@@ -399,55 +476,51 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             for (int a = 0; a < 3; a++) whole_grid = whole_grid && qc[a] <= 1 && qc[a] + 1 >= gp.dim[a] - 1;
             if (total < 2u * (uint32_t)k && !whole_grid && r2lim < 0.0) {
 #pragma unroll
-                for (int seg = 0; seg < 9; seg++) {
-                    seg_pack[seg] &= 0xffffu;
-                    seg_max[seg] = 0;
-                }
+                for (int seg = 0; seg < 9; seg++) seg_pack[seg] &= 0xffffu;
             }
         }
-#pragma unroll
-        for (int seg = 0; seg < 9; seg++) seg_max[seg] = wave_max_i32(seg_max[seg]);
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         const uint32_t cand_a = (uint32_t)(uintptr_t)(const lds_f32 *)cxyz;  // LDS byte address
-        const uint32_t pa_last = cand_a + 12u * (ncand - 1);
         const uint32_t wp_full = col_a + 4u * (SEL_SLOTS - 2) * PC_WAVE;  // (wp names the last written slot)
 #pragma unroll
         for (int seg = 0; seg < 9; seg++) {
-            const uint32_t start = seg_pack[seg] & 0xffffu;
-            const uint32_t end = start + (seg_pack[seg] >> 16);
-            const int tmax = seg_max[seg];
-            // two candidates per step: one ds_read2_b32 per coordinate, packed fp32 math
-            // (v_pk_add/mul/fma_f32); the next pair is requested as soon as this one is consumed
-            uint32_t pa = min(cand_a + 12u * start, pa_last);
+            // Two candidates per step: one ds_read2_b32 per coordinate, packed fp32 math
+            // (v_pk_add/mul/fma_f32); the next pair is requested as soon as this one is consumed.  A
+            // segment of odd length takes the candidate behind it along: the next record of the block (a
+            // point outside this query's cells, or the first point of the next row, which the query may
+            // meet again in its own walk -- the exact finish drops such a double) or the sentinel behind
+            // the block.  Extra candidates are real points with true distances: the result is exact
+            // either way, and leaving out the test of the second candidate saves two instructions a step.
+            uint32_t j0 = seg_pack[seg] & 0xffffu;
+            const uint32_t end = j0 + (seg_pack[seg] >> 16);
+            uint32_t pa = cand_a + 12u * j0;
             f32x2 nx, ny, nz;
             lds_read_xyz_pair(pa, nx, ny, nz);
-            uint32_t j0 = start, j1 = start + 1;
-#pragma nounroll
-            for (int t = 0; t < tmax; t += 2) {
-                lds_wait(nx, ny, nz);
-                const f32x2 dx = qx2 - nx, dy = qy2 - ny, dz = qz2 - nz;
-                pa = min(pa + 24u, pa_last);
-                lds_read_xyz_pair(pa, nx, ny, nz);
-                f32x2 d = dx * dx;
-                d = __builtin_elementwise_fma(dy, dy, d);
-                d = __builtin_elementwise_fma(dz, dz, d);
-                const uint32_t k0 = (__float_as_uint(d.x) & ~ORD_MASK) | j0;
-                const uint32_t k1 = (__float_as_uint(d.y) & ~ORD_MASK) | j1;
-                if (j0 < end && k0 < thr) {
-                    wp += 4u * PC_WAVE;
-                    lds_write_u32(wp, k0);
-                }
-                if (j1 < end && k1 < thr) {
-                    wp += 4u * PC_WAVE;
-                    lds_write_u32(wp, k1);
-                }
-                j0 += 2;
-                j1 += 2;
-                if (__any(wp >= wp_full)) drain();
+            for (;;) {
+                scan_pairs(j0, end, pa, wp, nx, ny, nz, qx2, qy2, qz2, thr, wp_full);
+                // (all lanes are back together here: the drain serves the whole wave, also the lanes whose
+                // segment had ended before)
+                if (__any(wp >= wp_full)) drain(DRAIN_ROUNDS);
+                if (!__any(j0 < end)) break;
             }
             lds_wait(nx, ny, nz);  // retire the last (unused) request
+#ifdef PC_COUNT
+            n_lock += (uint32_t)wave_max_i32((int)n_steps);
+            n_steps = 0;
+#endif
         }
-        drain();
+        drain(0xffffffffu);
+#ifdef PC_COUNT
+        {   // per 64-query batch: the longest lane's steps, rounds, drains
+            const int ms = (int)n_lock, mr = wave_max_i32((int)n_rounds), md = wave_max_i32((int)n_drains);
+            if (lane == 0) {
+                atomicAdd(A.flag_count + 24, (uint32_t)ms);
+                atomicAdd(A.flag_count + 25, (uint32_t)mr);
+                atomicAdd(A.flag_count + 27, (uint32_t)md);
+                atomicAdd(A.flag_count + 28, 1u);
+            }
+        }
+#endif
         if (!live) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
@@ -496,7 +569,8 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         for (int s = 0; s < KS; s++) {
             dd[s] = INFINITY;
             od[s] = L[s] & ORD_MASK;
-            if (L[s] != KEY_EMPTY) {
+            // (a key listed twice is the candidate a segment of odd length took along, met again in the walk)
+            if (L[s] != KEY_EMPTY && (s == 0 || L[s] != L[s - 1])) {
                 double cx, cy, cz;
                 int32_t cid;
                 TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2], cws[od[s]]), cx, cy, cz, cid);
@@ -544,7 +618,11 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         };
 #pragma nounroll
         for (int pass = 0; pass < KS; pass++) {
-            bool swapped = false;
+            // (a look at the order costs a seventh of a pass: most waves need one pass, then one look)
+            bool unordered = false;
+#pragma unroll
+            for (int s = 0; s + 1 < KS; s++) unordered |= dd[s] > dd[s + 1];
+            if (!__any(unordered)) break;
 #pragma unroll
             for (int s = 0; s + 1 < KS; s++) {
                 const double da = dd[s], db = dd[s + 1];
@@ -554,9 +632,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 dd[s + 1] = fmax(da, db);
                 od[s] = gt ? ob : oa;
                 od[s + 1] = gt ? oa : ob;
-                swapped |= gt;
             }
-            if (!__any(swapped)) break;
         }
         // equal distances (rare): order those neighbours by original index
         bool ties = false;
