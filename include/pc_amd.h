@@ -16,7 +16,12 @@
  *    app/Controllers/app_controller.py:428-441, 528-543), enqueues on `stream`
  *    (a hipStream_t passed as void*, NULL = default stream) and, where it returns host
  *    values, synchronises that stream before returning.
- *  - A context may be used by one thread at a time; use one context per thread.
+ *  - Threads: a context may be shared; its entry points take turns under a mutex held for the whole call (the
+ *    app's filter and reconstruction workers overlap, app/Controllers/app_controller.py:428-441, 528-543).
+ *    pc_last_error() returns the message of the calling thread's own last failure.
+ *  - Streams: pooled scratch goes back to the context when a call returns, ordered behind the work on that
+ *    call's stream; a call that arrives on another stream first waits for the previous call's stream, so a
+ *    stream handed to one call must stay alive until the next call on that context has begun.
  *  - Neighbour order everywhere: ascending squared distance computed in fp64 as
  *    ((dx*dx)+dy*dy)+dz*dz with dx = q - p; exact ties -> lower point index first.
  */
@@ -58,6 +63,9 @@ int pc_abi_version(void);
  * reference app/Core/pointcloud_preprocess.py:45-53 and :104-105. */
 int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_min[3], double out_max[3],
             void *stream);
+/* PointCloud.get_center(): the mean of the points (what translate(t, relative=False) subtracts).  Summed as a
+ * fixed two-level tree, so the last bits can differ from Open3D's sequential sum. */
+int pc_center(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_center[3], void *stream);
 /* In place on an fp64 cloud: if t != NULL p += t; then if has_scale p = (p - c) * s + c. */
 int pc_affine(pc_ctx *ctx, double *xyz_dev, int64_t n, const double *t, int has_scale, double s, const double *c,
               void *stream);
@@ -150,6 +158,12 @@ int pc_normals(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end,
 int pc_radius_count(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype, int64_t nq,
                     int64_t s_begin, int64_t s_end, double radius, int32_t *out_cnt_dev, void *stream);
 
+/* The selection step of PointCloud.remove_radius_outlier (filtering_adapter.py:94): mask[i] = cnt[i] > nb_points
+ * over the counts of pc_radius_count (or the capped counts of pc_knn); kept indices ascending; *n_kept = their
+ * number.  out_mask_dev / out_kept_dev may be NULL. */
+int pc_count_select(pc_ctx *ctx, const int32_t *cnt_dev, int64_t n, int32_t nb_points, uint8_t *out_mask_dev,
+                    int32_t *out_kept_dev, int64_t *n_kept, void *stream);
+
 /* PointCloud.compute_nearest_neighbor_distance (filtering_adapter.py:49,
  * app/Core/mesh_reconstruction.py:112): sqrt of the second-smallest d2, 0 if none. */
 int pc_nn_distance(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, double *out_dev, void *stream);
@@ -157,6 +171,10 @@ int pc_nn_distance(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_
 /* Row gather dst[i] = src[idx[i]] for m rows of 3 doubles (PointCloud.select_by_index). */
 int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
                    void *stream);
+
+/* The same for rows of 3 floats (clouds kept as fp32 because every coordinate is fp32-representable). */
+int pc_gather_rows_f32(pc_ctx *ctx, const float *src_dev, const int32_t *idx_dev, int64_t m, float *dst_dev,
+                       void *stream);
 
 /* PointCloud.orient_normals_consistent_tangent_plane(k) (app/Core/pointcloud_preprocess.py:115): turns the
  * n normals (n x 3 fp64, in place) so that they agree along the minimum spanning tree of the neighbour graph

@@ -26,6 +26,7 @@ SYMBOLS = [
     ("pc_status_string", C.c_char_p, [_i32]),
     ("pc_abi_version", _i32, []),
     ("pc_bbox", _i32, [_vp, _vp, _i32, _i64, _pd, _pd, _vp]),
+    ("pc_center", _i32, [_vp, _vp, _i32, _i64, _pd, _vp]),
     ("pc_affine", _i32, [_vp, _vp, _i64, _pd, _i32, _dbl, _pd, _vp]),
     ("pc_voxel_downsample", _i32, [_vp, _vp, _i32, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
     ("pc_voxel_assign", _i32, [_vp, _vp, _i32, _i64, _dbl, _vp, _pi32, _vp]),
@@ -46,6 +47,8 @@ SYMBOLS = [
     ("pc_radius_count", _i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _dbl, _vp, _vp]),
     ("pc_nn_distance", _i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     ("pc_gather_rows", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    ("pc_gather_rows_f32", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    ("pc_count_select", _i32, [_vp, _vp, _i64, _i32, _vp, _vp, _pi64, _vp]),
     ("pc_orient_normals", _i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     ("pc_icp_point_to_plane_terms", _i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
     ("pc_transform", _i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -15,7 +15,6 @@ constexpr int MAX_LEVELS = 8;  // resolution levels of one spatial index (pc_gri
 
 struct pc_ctx {
     int device = 0;
-    std::string err;
     // grow-only cache of device blocks so that per-frame calls do not hipMalloc
     struct Block {
         void *p;

@@ -9,11 +9,14 @@
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+// The message of the last failed call, kept per calling thread: two worker threads may share one context, and a
+// thread asks for the text of ITS failure (pc_last_error hands out a pointer into this thread's own string).
+static thread_local std::string tl_err;
+
 int pc_fail(pc_ctx *ctx, int status, const char *what, hipError_t e) {
-    if (ctx) {
-        ctx->err = std::string(pc_status_string(status)) + ": " + what;
-        if (e != hipSuccess) ctx->err += std::string(" (") + hipGetErrorString(e) + ")";
-    }
+    tl_err = std::string(pc_status_string(status)) + ": " + what;
+    if (e != hipSuccess) tl_err += std::string(" (") + hipGetErrorString(e) + ")";
+    (void)ctx;
     return status;
 }
 
@@ -104,7 +107,10 @@ void pc_destroy(pc_ctx *ctx) {
     delete ctx;
 }
 
-const char *pc_last_error(const pc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char *pc_last_error(const pc_ctx *ctx) {
+    (void)ctx;
+    return tl_err.empty() ? "no error" : tl_err.c_str();
+}
 
 }  // extern "C"
 
@@ -170,6 +176,48 @@ __global__ __launch_bounds__(64) void k_bbox_final(const double *__restrict__ pa
             out[a] = mn[a];
             out[3 + a] = mx[a];
         }
+    }
+}
+
+// Per-block partial sums of the coordinates (fixed block count and fixed trees: the same bits on every run).
+template <typename T>
+__global__ __launch_bounds__(256) void k_coord_sums(const T *__restrict__ xyz, int64_t n, double *__restrict__ partial) {
+    double s[3] = {0.0, 0.0, 0.0};
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b = (int64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) s[a] += (double)xyz[3 * i + a];
+    }
+    __shared__ double red[3][256];
+#pragma unroll
+    for (int a = 0; a < 3; a++) red[a][threadIdx.x] = s[a];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) red[a][threadIdx.x] += red[a][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[3 * blockIdx.x + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(64) void k_coord_sums_final(const double *__restrict__ partial, int nb, double *__restrict__ out) {
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nb; b += 64) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) s[a] += partial[3 * b + a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[a] += __shfl_down(s[a], o, 64);
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s[0];
+        out[1] = s[1];
+        out[2] = s[2];
     }
 }
 
@@ -445,8 +493,9 @@ __global__ __launch_bounds__(256) void k_voxel_reduce(const T *__restrict__ xyz,
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_rows(const double *__restrict__ src, const int32_t *__restrict__ idx,
-                                                      int64_t m3, double *__restrict__ dst) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_rows(const T *__restrict__ src, const int32_t *__restrict__ idx,
+                                                      int64_t m3, T *__restrict__ dst) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m3) return;
     dst[i] = src[3 * (size_t)idx[i / 3] + (i % 3)];
@@ -519,6 +568,31 @@ int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_m
     return bbox_impl(ctx, xyz_dev, dtype, n, out_min, out_max, (hipStream_t)stream);
 }
 
+int pc_center(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_center[3], void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || !out_center || n < 0 || (n > 0 && !xyz_dev) || (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_center");
+    PC_HIP(hipSetDevice(ctx->device));
+    out_center[0] = out_center[1] = out_center[2] = 0.0;
+    if (n == 0) return PC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = 512;
+    Scratch part(ctx, sizeof(double) * 3 * (size_t)(nb + 1));
+    if (!part.ok()) return pc_fail(ctx, PC_NOMEM, "centre scratch");
+    double *p = part.as<double>();
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_coord_sums<float>, dim3(nb), dim3(256), 0, st, (const float *)xyz_dev, n, p);
+    else
+        hipLaunchKernelGGL(k_coord_sums<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz_dev, n, p);
+    hipLaunchKernelGGL(k_coord_sums_final, dim3(1), dim3(64), 0, st, p, nb, p + 3 * (size_t)nb);
+    PC_HIP(hipGetLastError());
+    double *h = reinterpret_cast<double *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(h, p + 3 * (size_t)nb, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    for (int a = 0; a < 3; a++) out_center[a] = h[a] / (double)n;
+    return PC_OK;
+}
+
 int pc_affine(pc_ctx *ctx, double *xyz_dev, int64_t n, const double *t, int has_scale, double s, const double *c,
               void *stream) {
     PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
@@ -552,6 +626,9 @@ int pc_voxel_assign(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, doub
     }
     double mn[3], mx[3];
     PC_TRY(bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st));
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
+            return pc_fail(ctx, PC_BAD_ARG, "non-finite coordinates: the cloud has no finite bounding box");
     GridParams gp{};
     PC_TRY(voxel_params(ctx, mn, mx, voxel_size, &gp));
     if (out_dims)
@@ -582,6 +659,9 @@ int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const doubl
     if (n == 0) return PC_OK;
     double mn[3], mx[3];
     PC_TRY(bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st));
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
+            return pc_fail(ctx, PC_BAD_ARG, "non-finite coordinates: the cloud has no finite bounding box");
     GridParams gp{};
     PC_TRY(voxel_params(ctx, mn, mx, voxel_size, &gp));
 
@@ -644,6 +724,13 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         delete g;
         return rc;
     }
+    // NaN coordinates never reach the box (fmin / fmax skip them: an all-NaN axis leaves +inf / -inf) and
+    // infinite ones make it infinite: neither can be put into cells
+    for (int a = 0; a < 3 && n > 0; a++)
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mx[a] < mn[a]) {
+            delete g;
+            return pc_fail(ctx, PC_BAD_ARG, "non-finite coordinates: the cloud has no finite bounding box");
+        }
     for (int a = 0; a < 3; a++) {
         g->bb_min[a] = mn[a];
         g->bb_max[a] = mx[a];
@@ -675,14 +762,15 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
     // u32 cell keys: below 2^32 cells.  A dense offset table is kept while it stays within
     // 8 n + 4096 cells; emptier grids use the sparse index (binary search over the sorted keys).
     auto fit_dims = [&](double c, int32_t dim[3]) {
-        for (;;) {
+        for (int it = 0;; it++) {
             double tot = 1.0;
             for (int a = 0; a < 3; a++) {
                 double d = std::min(floor(ext[a] / c) + 1.0, 2.0e9);
+                if (!(d >= 1.0)) d = 1.0;  // (never with a finite box; keeps the cast defined)
                 dim[a] = (int32_t)d;
                 tot *= d;
             }
-            if (tot <= 4.0e9) return c;
+            if (tot <= 4.0e9 || it >= 4096) return c;  // (1.1^4096 overflows any finite extent long before)
             c *= 1.1;
         }
     };
@@ -1016,7 +1104,19 @@ int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, i
     if (!ctx || m < 0 || (m > 0 && (!src_dev || !idx_dev || !dst_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_gather_rows");
     PC_HIP(hipSetDevice(ctx->device));
     if (m == 0) return PC_OK;
-    hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(3 * m, 256)), dim3(256), 0, (hipStream_t)stream, src_dev,
+    hipLaunchKernelGGL(k_gather_rows<double>, dim3(blocks_for(3 * m, 256)), dim3(256), 0, (hipStream_t)stream, src_dev,
+                       idx_dev, 3 * m, dst_dev);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_gather_rows_f32(pc_ctx *ctx, const float *src_dev, const int32_t *idx_dev, int64_t m, float *dst_dev,
+                       void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || m < 0 || (m > 0 && (!src_dev || !idx_dev || !dst_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_gather_rows_f32");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (m == 0) return PC_OK;
+    hipLaunchKernelGGL(k_gather_rows<float>, dim3(blocks_for(3 * m, 256)), dim3(256), 0, (hipStream_t)stream, src_dev,
                        idx_dev, 3 * m, dst_dev);
     PC_HIP(hipGetLastError());
     return PC_OK;

@@ -128,11 +128,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_scan(ScanArgs A) {
             for (int a = 0; a < 3; a++) {
                 if (lo[a] > 0) {
                     whole = false;
-                    dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)lo[a] * gp.cell));
+                    dmin = fmin(dmin, (qv[a] - gp.o[a]) - (double)lo[a] * gp.cell);  // (in offsets from the origin, like the cell keys)
                 }
                 if (hi[a] < gp.dim[a] - 1) {
                     whole = false;
-                    dmin = fmin(dmin, (gp.o[a] + (double)(hi[a] + 1) * gp.cell) - qv[a]);
+                    dmin = fmin(dmin, (double)(hi[a] + 1) * gp.cell - (qv[a] - gp.o[a]));
                 }
             }
             if (whole) break;
@@ -263,6 +263,12 @@ __global__ __launch_bounds__(256) void k_sor_flags(const double *__restrict__ av
         const double v = avg[i];
         flags[i] = (v > 0 && v < thr) ? 1 : 0;
     }
+}
+
+__global__ __launch_bounds__(256) void k_count_flags(const int32_t *__restrict__ cnt, int64_t n, int32_t nb,
+                                                      uint8_t *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = cnt[i] > nb ? 1 : 0;
 }
 
 int sor_reduce(pc_ctx *ctx, int what, const double *avg, int64_t n, double mean, double out[2], hipStream_t st) {
@@ -410,6 +416,22 @@ int pc_sor_select(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshol
     if (!tmp.ok()) return pc_fail(ctx, PC_NOMEM, "mask scratch");
     uint8_t *flags = out_mask_dev ? out_mask_dev : tmp.as<uint8_t>();
     hipLaunchKernelGGL(k_sor_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, avg_dev, n, threshold, flags);
+    PC_HIP(hipGetLastError());
+    return pc_compact_flags(ctx, flags, n, out_kept_dev, n_kept, st);
+}
+
+int pc_count_select(pc_ctx *ctx, const int32_t *cnt_dev, int64_t n, int32_t nb_points, uint8_t *out_mask_dev,
+                    int32_t *out_kept_dev, int64_t *n_kept, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || n < 0 || (n > 0 && !cnt_dev) || !n_kept) return pc_fail(ctx, PC_BAD_ARG, "pc_count_select");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *n_kept = 0;
+    if (n == 0) return PC_OK;
+    Scratch tmp(ctx, (size_t)n);
+    if (!tmp.ok()) return pc_fail(ctx, PC_NOMEM, "mask scratch");
+    uint8_t *flags = out_mask_dev ? out_mask_dev : tmp.as<uint8_t>();
+    hipLaunchKernelGGL(k_count_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cnt_dev, n, nb_points, flags);
     PC_HIP(hipGetLastError());
     return pc_compact_flags(ctx, flags, n, out_kept_dev, n_kept, st);
 }

@@ -177,11 +177,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         const int nlo = max(c[a] - 1, 0), nhi = min(c[a] + 1, gp.dim[a] - 1);
         if (nlo > 0) {
             whole = false;
-            dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)nlo * gp.cell));
+            dmin = fmin(dmin, (qv[a] - gp.o[a]) - (double)nlo * gp.cell);  // (in offsets from the origin, like the cell keys)
         }
         if (nhi < gp.dim[a] - 1) {
             whole = false;
-            dmin = fmin(dmin, (gp.o[a] + (double)(nhi + 1) * gp.cell) - qv[a]);
+            dmin = fmin(dmin, (double)(nhi + 1) * gp.cell - (qv[a] - gp.o[a]));
         }
     }
     double bound = INFINITY;

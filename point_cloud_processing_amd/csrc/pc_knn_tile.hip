@@ -474,7 +474,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             }
             A.tile_list = l->full_tiles + f0;
             const int nw = uneven_waves(f1 - f0);
-            const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+            const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (3 * MAX_ROWS + 4) +
                                (A.halves ? 2 : 1) * sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
                                nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
             if (getenv("PC_AMD_DEBUG"))
@@ -506,7 +506,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             if (getenv("PC_AMD_DEBUG"))
                 fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],
                         l->tile[2], l->tile_cap, nw, (long long)nt);
-            const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (2 * MAX_ROWS + 4) +
+            const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (3 * MAX_ROWS + 4) +
                                (A.halves ? 2 : 1) * sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
                                nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
             if (g->dtype == PC_F32) {

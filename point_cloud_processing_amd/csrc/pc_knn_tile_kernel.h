@@ -16,7 +16,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float lds_f32;    // 32-bit LDS addresses: no 64-bit pointer math
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 constexpr int MAX_ROWS = 64;  // (tile_y + 2) * (tile_z + 2) must fit one wave
-constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most
+constexpr int MAX_NX = 7;     // tile_x + 2 cells per block row at most (MAX_NX + 1 is a power of two: table indexing)
 constexpr int MAX_TILE_WAVES = 4;  // waves of one workgroup, all working on the same staged block
 constexpr int UNEVEN_CAP = 1024;   // candidate capacity of the tiles of multi-level indexes
 constexpr int SEL_SLOTS = 16; // parked keys per lane between two sorted insertions
@@ -184,7 +184,8 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     float *cxyz = reinterpret_cast<float *>(smem), *cws = cxyz + 3 * cstride;
     uint32_t *row_src = reinterpret_cast<uint32_t *>(cws + cstride);                               // [64] begin
     uint32_t *row_off = row_src + MAX_ROWS;                                                        // [65] offsets
-    uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_off + MAX_ROWS + 4);                     // [64][MAX_NX+1]
+    uint32_t *row_key = row_off + MAX_ROWS + 4;                                                    // [64] key of the row's cell 0
+    uint16_t *cell_off = reinterpret_cast<uint16_t *>(row_key + MAX_ROWS);                         // [64][MAX_NX+1]
     // one area of lane-private columns: parked keys during the filter, result order afterwards
     const int tid = threadIdx.x, lane = tid & (PC_WAVE - 1), wid = tid >> 6, nthr = blockDim.x;
     // (one such area per wave)
@@ -220,9 +221,13 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
 
     // ---- row table: lane r describes block row r -------------------------------------------------
     uint32_t row_begin = 0, row_cnt = 0, q_begin = 0, q_cnt = 0;
+    uint32_t my_row_key = 0;
     if (lane < nrows) {
-        const int y = lo[1] + lane % nry, z = lo[2] + lane / nry;
-        const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+        // (lane / nry without an integer division: exact for these small numbers)
+        const int rz0 = (int)(((float)lane + 0.5f) * (1.0f / (float)nry));
+        const int y = lo[1] + lane - rz0 * nry, z = lo[2] + rz0;
+        const int64_t row = (int64_t)(((uint32_t)z * (uint32_t)gp.dim[1] + (uint32_t)y) * (uint32_t)gp.dim[0]);  // < 2^32 cells
+        my_row_key = (uint32_t)row;
         row_begin = cell_begin(A.ci, row + lo[0]);
         row_cnt = cell_begin(A.ci, row + hi[0] + 1) - row_begin;
         if (y >= c0[1] && y <= c1[1] && z >= c0[2] && z <= c1[2]) {  // a row of the tile itself
@@ -289,6 +294,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     // candidate follows from the row offsets, and four 16-byte loads are in flight per lane
     row_src[lane] = row_begin;
     row_off[lane] = cand_off;
+    row_key[lane] = my_row_key;
     if (lane == 0) row_off[MAX_ROWS] = ncand;
     __syncthreads();
     if (!overfull) {
@@ -324,17 +330,17 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     if (!overfull && tid < 6) cxyz[3 * ncand + tid] = 1e30f;
     // block-relative offset of every cell boundary of every block row
     const int nx = hi[0] - lo[0] + 1;
-    for (int e = tid; e < nrows * (nx + 1); e += nthr) {
-        const int r = e / (nx + 1), i = e - r * (nx + 1);
-        const int y = lo[1] + r % nry, z = lo[2] + r / nry;
-        const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
-        cell_off[r * (MAX_NX + 1) + i] = (uint16_t)(row_off[r] + (cell_begin(A.ci, row + lo[0] + i) - row_src[r]));
+    for (int e = tid; e < nrows * (MAX_NX + 1); e += nthr) {  // (entry e of the table: row e / 8, boundary e % 8)
+        const int r = e >> 3, i = e & MAX_NX;
+        if (i <= nx)
+            cell_off[e] = (uint16_t)(row_off[r] + (cell_begin(A.ci, (int64_t)row_key[r] + lo[0] + i) - row_src[r]));
     }
     __syncthreads();
     if (halves) {
         // first high-half record of every block cell (the records of a cell are ordered by that bit)
-        for (int e = tid; e < nrows * nx; e += nthr) {
-            const int r = e / nx, i = e - r * nx;
+        for (int e = tid; e < nrows * (MAX_NX + 1); e += nthr) {
+            const int r = e >> 3, i = e & MAX_NX;
+            if (i >= nx) continue;
             int a = cell_off[r * (MAX_NX + 1) + i], b = cell_off[r * (MAX_NX + 1) + i + 1];
             while (a < b) {
                 const int m = (a + b) >> 1;
@@ -559,7 +565,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         if (!live) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
-        const double qv[3] = {qxd, qyd, qzd};
+        // distance to the nearest face of the scanned cells, measured like the cell keys: in offsets from the
+        // grid origin (a face position added to a far origin would round at the origin's magnitude)
+        const double qv[3] = {qxd - gp.o[0], qyd - gp.o[1], qzd - gp.o[2]};
         bool whole = true;
         double dmin = INFINITY;
 #pragma unroll
@@ -567,15 +575,15 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             const int nlo = max(qc[a] - 1, 0), nhi = min(qc[a] + 1, gp.dim[a] - 1);
             if (nlo > 0) {
                 whole = false;
-                dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)nlo * gp.cell));
+                dmin = fmin(dmin, qv[a] - (double)nlo * gp.cell);
             }
             if (nhi < gp.dim[a] - 1) {
                 whole = false;
-                dmin = fmin(dmin, (gp.o[a] + (double)(nhi + 1) * gp.cell) - qv[a]);
+                dmin = fmin(dmin, (double)(nhi + 1) * gp.cell - qv[a]);
             }
             if (a == 0 && trim != 0) {  // the half-cell left out begins in the middle of its cell
                 whole = false;
-                const double mid = gp.o[0] + ((double)(qc[0] + trim) + 0.5) * gp.cell;
+                const double mid = ((double)(qc[0] + trim) + 0.5) * gp.cell;
                 dmin = fmin(dmin, trim > 0 ? mid - qv[0] : qv[0] - mid);
             }
         }
@@ -596,37 +604,51 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
         }
 
+        // The KS listed candidates re-measured in fp64, without a branch: every slot is read and measured (an
+        // empty slot or the second copy of a double reads candidate 0 and is left out afterwards), so that all
+        // the LDS reads are in flight together.
+        const double r2eff = r2lim >= 0.0 ? r2lim : INFINITY;
         double dd[KS];
         uint32_t od[KS];
         int nsafe = 0, cnt = 0, nvalid = 0;
-        double dmax = 0.0;  // farthest listed candidate: bounds the k-th distance when k are listed
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            dd[s] = INFINITY;
-            od[s] = L[s] & ORD_MASK;
             // (a key listed twice is the candidate a segment of odd length took along, met again in the walk)
-            if (L[s] != KEY_EMPTY && (s == 0 || L[s] != L[s - 1])) {
-                double cx, cy, cz;
-                int32_t cid;
-                TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2], cws[od[s]]), cx, cy, cz, cid);
-                const double dx = qxd - cx, dy = qyd - cy, dz = qzd - cz;
-                double d = dx * dx;
-                d += dy * dy;
-                d += dz * dz;
-                nvalid++;
-                dmax = fmax(dmax, d);
-                if (d < bound) {
-                    nsafe++;
-                    if (!(r2lim >= 0.0 && !(d < r2lim))) {
-                        dd[s] = d;
-                        cnt++;
-                    }
-                }
-            }
+            const bool valid = L[s] != KEY_EMPTY && (s == 0 || L[s] != L[s - 1]);
+            od[s] = valid ? (L[s] & ORD_MASK) : 0u;
+            double cx, cy, cz;
+            int32_t cid;
+            // (fp64 grids fetch the record by its sorted position: position 0 for a slot that is left out --
+            // candidate 0 of a block without candidates was never staged)
+            TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2],
+                                                 TileRec<REC>::kRelative && valid ? cws[od[s]] : 0.f), cx, cy, cz, cid);
+            const double dx = qxd - cx, dy = qyd - cy, dz = qzd - cz;
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            const bool safe = valid && d < bound, in = safe && d < r2eff;
+            nvalid += valid ? 1 : 0;
+            nsafe += safe ? 1 : 0;
+            cnt += in ? 1 : 0;
+            dd[s] = in ? d : INFINITY;
         }
         const bool ok = nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim);
         if (!ok) {
-            float ubf = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
+            // an upper bound of the k-th distance when k candidates are listed: the largest listed key, with
+            // what truncation (2^-12) and the fp32 measurement (the rounded frame of fp64 grids) can hide
+            float ubf = INFINITY;
+            if (nvalid >= k) {
+                uint32_t last = 0;
+#pragma unroll
+                for (int s = 0; s < KS; s++) last = L[s] != KEY_EMPTY ? L[s] : last;
+                const double th = (double)__uint_as_float(last & ~ORD_MASK) * (1.0 + 2.44140625e-4);
+                if (TileRec<REC>::kRelative) {
+                    const double rt = sqrt(th) * (1.0 + 1e-6) + 4.76837158203125e-07 * bext;
+                    ubf = (float)(rt * rt * (1.0 + 1e-6));
+                } else {
+                    ubf = (float)(th * (1.0 + 2e-6));
+                }
+            }
             if (A.qflag_in) ubf = fminf(ubf, A.qub_arr[qid]);
             if (A.qflag_out) {
                 A.qflag_out[qid] = 1;

@@ -54,11 +54,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 hi[a] = min(c + R, gp.dim[a] - 1);
                 if (lo[a] > 0) {
                     whole = false;
-                    dmin = fmin(dmin, qv[a] - (gp.o[a] + (double)lo[a] * gp.cell));
+                    dmin = fmin(dmin, (qv[a] - gp.o[a]) - (double)lo[a] * gp.cell);  // (in offsets from the origin, like the cell keys)
                 }
                 if (hi[a] < gp.dim[a] - 1) {
                     whole = false;
-                    dmin = fmin(dmin, (gp.o[a] + (double)(hi[a] + 1) * gp.cell) - qv[a]);
+                    dmin = fmin(dmin, (double)(hi[a] + 1) * gp.cell - (qv[a] - gp.o[a]));
                 }
             }
             double b2 = INFINITY;  // no point outside the block is closer than sqrt(b2)
