@@ -57,8 +57,18 @@ class OracleEngine:
     def icp_session(self, src, tgt, tgt_normals):
         return OracleIcpSession(src, tgt, tgt_normals)
 
+    @staticmethod
+    def to_host(a):
+        return a
+
     def bbox(self, pts, cache):
         return O.bbox(pts)
+
+    def center(self, pts, cache):
+        return np.asarray(pts, dtype=np.float64).mean(axis=0)
+
+    def radius_outlier(self, pts, nb_points, radius, cache):
+        return np.nonzero(O.radius_count(pts, radius) > int(nb_points))[0]
 
     def affine(self, pts, cache, t, s, c):
         out = np.array(pts, dtype=np.float64, copy=True)

@@ -48,14 +48,14 @@ def preprocess_point_cloud(pcd, voxel_size: float = 0.02):
     input object itself is returned with normals (pointcloud_preprocess.py:94-99).
     """
     cloud = wrap(pcd)
-    n_before = len(cloud.points)
+    n_before = len(cloud)
     if voxel_size is not None and voxel_size > 0:
         print(f"[Preprocess] Voxel downsample with size = {voxel_size}")
         proc = cloud.voxel_down_sample(voxel_size)
     else:
         print("[Preprocess] Skip voxel downsample (use full cloud)")
         proc = cloud
-    print(f"[Preprocess] Points: {n_before} -> {len(proc.points)}")
+    print(f"[Preprocess] Points: {n_before} -> {len(proc)}")
 
     extent = proc.get_axis_aligned_bounding_box().get_max_extent()
     radius = extent * NORMAL_RADIUS_FRACTION

@@ -104,7 +104,7 @@ def filter_pcd(pcd, settings: Optional[FilterSettings] = None):
         if a.with_radius and s.use_radius:
             cl, _ = cl.remove_radius_outlier(nb_points=int(a.rad_nb), radius=float(a.rad_r))
         a.cloud = cl
-        a.drop = 1.0 - (len(cl.points) / n0)
+        a.drop = 1.0 - (len(cl) / n0)  # (the row count: no copy of the points)
         return a
 
     best = run(_Attempt(s.std_ratio, s.nb_radius, radius, True))
@@ -127,7 +127,7 @@ def filter_pcd(pcd, settings: Optional[FilterSettings] = None):
 
     if s.debug:
         print(
-            f"[Filter] n0={n0} -> n={len(best.cloud.points)} (drop={best.drop*100:.1f}%), "
+            f"[Filter] n0={n0} -> n={len(best.cloud)} (drop={best.drop*100:.1f}%), "
             f"nn_med={nn_med:.5f}, "
             f"stat={'on' if s.use_stat else 'off'}(nb={s.nb_stat}, sr={s.std_ratio}), "
             f"radius={'on' if (s.use_radius and radius_on) else 'off'}"

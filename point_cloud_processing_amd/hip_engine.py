@@ -127,18 +127,34 @@ class HipEngine:
     def upload(self, a: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(np.require(a, requirements=["C", "W"])).to(self.device)  # (read-only views are copied)
 
-    def dev_points(self, pts: np.ndarray, cache: dict) -> torch.Tensor:
-        """Device copy of a cloud's coordinates.  fp32 storage when every coordinate is
-        exactly fp32-representable (then nothing is lost), fp64 otherwise."""
+    device_resident = True  # results of the *_dev methods stay in HBM as torch tensors
+
+    @staticmethod
+    def to_host(a) -> np.ndarray:
+        """Host copy of an engine array (float arrays come back as float64, exactly)."""
+        if isinstance(a, torch.Tensor):
+            a = a.cpu().numpy()
+        return a.astype(np.float64) if a.dtype == np.float32 else a
+
+    def dev_points(self, pts, cache: dict) -> torch.Tensor:
+        """Device copy of a cloud's coordinates (``pts``: a host array, or a device array, which is used as
+        it is).  fp32 storage when every coordinate of a host array is exactly fp32-representable (then
+        nothing is lost), fp64 otherwise."""
         t = cache.get("xyz")
         if t is None:
-            p32 = pts.astype(np.float32)
-            if np.array_equal(p32.astype(np.float64), pts):
-                t = self.upload(p32)
+            if isinstance(pts, torch.Tensor):
+                t = pts
             else:
-                t = self.upload(pts)
+                p32 = pts.astype(np.float32)
+                t = self.upload(p32 if np.array_equal(p32.astype(np.float64), pts) else pts)
             cache["xyz"] = t
         return t
+
+    def dev_f64(self, a) -> torch.Tensor:
+        """An (N, 3) attribute as a float64 device array (uploaded, or widened, when it is not one yet)."""
+        if isinstance(a, torch.Tensor):
+            return a if a.dtype == torch.float64 else a.to(torch.float64)
+        return self.upload(np.asarray(a, dtype=np.float64))
 
     @staticmethod
     def _dt(t: torch.Tensor) -> int:
@@ -164,19 +180,31 @@ class HipEngine:
             cache["bbox"] = b
         return b
 
-    def affine(self, pts, cache, t, s, c):
-        d = self.upload(np.asarray(pts, dtype=np.float64))
+    def center(self, pts, cache):
+        t = self.dev_points(pts, cache)
+        out = (C.c_double * 3)()
+        self._check(self.lib.pc_center(self.ctx, _ptr(t), self._dt(t), len(pts), out, self.stream()), "pc_center")
+        return np.array(out[:], dtype=np.float64)
+
+    def affine_dev(self, pts, cache, t, s, c) -> torch.Tensor:
+        """The edited coordinates as a new float64 device array (the argument is left alone)."""
+        d = self.dev_f64(pts)
+        if d is pts or d is cache.get("xyz"):
+            d = d.clone()
         tt = None if t is None else (C.c_double * 3)(*[float(v) for v in t])
         cc = (C.c_double * 3)(*[float(v) for v in (c if c is not None else (0.0, 0.0, 0.0))])
         self._check(self.lib.pc_affine(self.ctx, _ptr(d), len(pts), tt, 0 if s is None else 1,
                                        0.0 if s is None else float(s), cc, self.stream()), "pc_affine")
-        return d.cpu().numpy()
+        return d
 
-    def voxel_downsample(self, pts, nrm, col, vs, cache):
+    def affine(self, pts, cache, t, s, c):
+        return self.affine_dev(pts, cache, t, s, c).cpu().numpy()
+
+    def voxel_downsample_dev(self, pts, nrm, col, vs, cache):
         n = len(pts)
         t = self.dev_points(pts, cache)
-        dn = None if nrm is None else self.upload(nrm)
-        dc = None if col is None else self.upload(col)
+        dn = None if nrm is None else self.dev_f64(nrm)
+        dc = None if col is None else self.dev_f64(col)
         op = self.empty((n, 3), torch.float64)
         on = None if nrm is None else self.empty((n, 3), torch.float64)
         oc = None if col is None else self.empty((n, 3), torch.float64)
@@ -185,8 +213,12 @@ class HipEngine:
                                                  _ptr(op), _ptr(on), _ptr(oc), None, None, C.byref(m), self.stream()),
                     "pc_voxel_downsample")
         m = m.value
-        return (op[:m].cpu().numpy(), None if on is None else on[:m].cpu().numpy(),
-                None if oc is None else oc[:m].cpu().numpy())
+        # (own storage of m rows each: the n-row output buffers go back to the allocator)
+        return (op[:m].clone(), None if on is None else on[:m].clone(), None if oc is None else oc[:m].clone())
+
+    def voxel_downsample(self, pts, nrm, col, vs, cache):
+        p, n, c = self.voxel_downsample_dev(pts, nrm, col, vs, cache)
+        return p.cpu().numpy(), None if n is None else n.cpu().numpy(), None if c is None else c.cpu().numpy()
 
     def voxel_assign(self, pts, vs, cache=None):
         cache = {} if cache is None else cache
@@ -270,17 +302,61 @@ class HipEngine:
             std = float(np.sqrt(np.float64(sq.value) / np.float64(valid.value - 1)))
         return mean, std, mean + std_ratio * std, valid.value
 
-    def sor(self, pts, k, std_ratio, cache):
+    def sor_dev(self, pts, k, std_ratio, cache):
+        """Kept indices of the statistical filter, still on the device (a LazyIndices)."""
+        from .geometry import LazyIndices
+
         avg = self.sor_avg_dev(pts, k, cache)
         mean, std, thr, valid = self.sor_stats(avg, std_ratio)
         if valid == 0:
-            return np.zeros(0, dtype=np.int64)
+            return LazyIndices(self, self.empty((0,), torch.int32), 0)
         n = avg.numel()
         kept = self.empty((n,), torch.int32)
         nk = C.c_int64(0)
         self._check(self.lib.pc_sor_select(self.ctx, _ptr(avg), n, float(thr), None, _ptr(kept), C.byref(nk),
                                            self.stream()), "pc_sor_select")
-        return kept[: nk.value].cpu().numpy().astype(np.int64)
+        return LazyIndices(self, kept[: nk.value], nk.value)
+
+    def sor(self, pts, k, std_ratio, cache):
+        return self.sor_dev(pts, k, std_ratio, cache).host()
+
+    def radius_outlier_dev(self, pts, nb_points, radius, cache):
+        """Indices of the points with more than nb_points neighbours inside the radius (self included): capped
+        counts from the hybrid search, then an ordered select; nothing visits the host but the count."""
+        from .geometry import LazyIndices
+
+        n = len(pts)
+        cnt = self.radius_count_dev(pts, radius, cache, cap=int(nb_points) + 1)
+        kept = self.empty((n,), torch.int32)
+        nk = C.c_int64(0)
+        self._check(self.lib.pc_count_select(self.ctx, _ptr(cnt), n, int(nb_points), None, _ptr(kept), C.byref(nk),
+                                             self.stream()), "pc_count_select")
+        return LazyIndices(self, kept[: nk.value], nk.value)
+
+    def radius_outlier(self, pts, nb_points, radius, cache):
+        return self.radius_outlier_dev(pts, nb_points, radius, cache).host()
+
+    def select(self, arrs: dict, idx, m: int, cache: dict, child_cache: dict) -> dict:
+        """Rows ``idx`` (a device int32 array, or host indices) of every given (N, 3) attribute, gathered on the
+        device.  A cloud held as fp32 (exactly representable coordinates) stays fp32: the child's index is
+        built from the gathered fp32 rows."""
+        if not isinstance(idx, torch.Tensor):
+            idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+        out = {}
+        for name, a in arrs.items():
+            xyz = cache.get("xyz") if name == "points" else None
+            if xyz is not None and xyz.dtype == torch.float32:
+                dst = self.empty((m, 3), torch.float32)
+                self._check(self.lib.pc_gather_rows_f32(self.ctx, _ptr(xyz), _ptr(idx), m, _ptr(dst), self.stream()),
+                            "pc_gather_rows_f32")
+                child_cache["xyz"] = dst
+            else:
+                src = xyz if xyz is not None else self.dev_f64(a)
+                dst = self.empty((m, 3), torch.float64)
+                self._check(self.lib.pc_gather_rows(self.ctx, _ptr(src), _ptr(idx), m, _ptr(dst), self.stream()),
+                            "pc_gather_rows")
+            out[name] = dst
+        return out
 
     # -- sharded variants: rank r of W answers sorted positions [r*n/W, (r+1)*n/W) --------------------
     def _owned(self, g: DeviceGrid, rank: int, world: int):
@@ -318,16 +394,19 @@ class HipEngine:
         o = torch.from_numpy(owned).to(self.device)
         return owned, idx[o].cpu().numpy(), d2[o].cpu().numpy(), cnt[o].cpu().numpy()
 
-    def normals(self, pts, k, radius, prior, cache):
+    def normals_dev(self, pts, k, radius, prior, cache) -> torch.Tensor:
         g = self.grid(pts, cache, k)
         n = len(pts)
         out = self.empty((n, 3), torch.float64)
-        dp = None if prior is None else self.upload(np.asarray(prior, dtype=np.float64))
+        dp = None if prior is None else self.dev_f64(prior)
         self._check(self.lib.pc_normals(self.ctx, g.h, 0, n, int(k), float(radius), _ptr(dp), _ptr(out),
                                         self.stream()), "pc_normals")
-        return out.cpu().numpy()
+        return out
 
-    def radius_count(self, pts, radius, cache, cap=None):
+    def normals(self, pts, k, radius, prior, cache):
+        return self.normals_dev(pts, k, radius, prior, cache).cpu().numpy()
+
+    def radius_count_dev(self, pts, radius, cache, cap=None) -> torch.Tensor:
         """Neighbours with d2 < radius^2 (self included).  With `cap` the result is min(count, cap): that is
         all remove_radius_outlier needs (count > nb_points), and it is the hybrid search
         kNN(k = cap, radius) on the tile kernel instead of a full ball count."""
@@ -337,19 +416,22 @@ class HipEngine:
             g = self.grid(pts, cache, int(cap))
             self._check(self.lib.pc_knn(self.ctx, g.h, None, _lib.PC_F64, n, int(cap), float(radius), None, None,
                                         _lib.PC_F32, _ptr(cnt), self.stream()), "pc_knn")
-            return cnt.cpu().numpy()
+            return cnt
         g = self.grid(pts, cache, 8)
         if float(radius) > 2.0 * g.info()["cell"]:
             # a ball spanning many cells: one ring of radius-sized cells beats many rings of small ones
             g = DeviceGrid(self, self.dev_points(pts, cache), n, 0, cell=float(radius))
         self._check(self.lib.pc_radius_count(self.ctx, g.h, None, _lib.PC_F64, 0, 0, n, float(radius), _ptr(cnt),
                                              self.stream()), "pc_radius_count")
-        out = cnt.cpu().numpy()
+        return cnt
+
+    def radius_count(self, pts, radius, cache, cap=None):
+        out = self.radius_count_dev(pts, radius, cache, cap).cpu().numpy()
         return out if cap is None else np.minimum(out, int(cap))
 
-    def orient_normals(self, pts, nrm, k, cache):
+    def orient_normals_dev(self, pts, nrm, k, cache):
         """Normals turned to agree along the spanning tree of the k-neighbour graph; the neighbour rows
-        never leave the device.  Returns (normals, number of connected pieces)."""
+        never leave the device.  Returns (normals as a new device array, number of connected pieces)."""
         n = len(pts)
         g = self.grid(pts, cache, k)
         t = self.dev_points(pts, cache)
@@ -357,11 +439,17 @@ class HipEngine:
         cnt = self.empty((n,), torch.int32)
         self._check(self.lib.pc_knn(self.ctx, g.h, None, _lib.PC_F64, n, int(k), -1.0, _ptr(idx), None, _lib.PC_F32,
                                     _ptr(cnt), self.stream()), "pc_knn")
-        dn = self.upload(np.asarray(nrm, dtype=np.float64))
+        dn = self.dev_f64(nrm)
+        if dn is nrm:
+            dn = dn.clone()
         pieces = C.c_int64(0)
         self._check(self.lib.pc_orient_normals(self.ctx, _ptr(t), self._dt(t), _ptr(dn), _ptr(idx), _ptr(cnt), n, int(k),
                                                C.byref(pieces), self.stream()), "pc_orient_normals")
-        return dn.cpu().numpy(), int(pieces.value)
+        return dn, int(pieces.value)
+
+    def orient_normals(self, pts, nrm, k, cache):
+        dn, pieces = self.orient_normals_dev(pts, nrm, k, cache)
+        return dn.cpu().numpy(), pieces
 
     def icp_session(self, src, tgt, tgt_normals) -> HipIcpSession:
         return HipIcpSession(self, src, tgt, tgt_normals)

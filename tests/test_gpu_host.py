@@ -193,3 +193,63 @@ def test_calls_alternate_between_streams(hip, oracle):
         with torch.cuda.stream(s1 if it % 2 == 0 else s2):
             idx, d2, cnt = hip.knn(p, None, 16, -1.0, {})
         assert np.array_equal(idx, want[0]) and np.array_equal(d2, want[1])
+
+
+def test_chains_stay_on_the_device(hip, oracle):
+    """normalise -> voxel -> normals and statistical -> radius filter: the attributes of the intermediate and
+    final clouds live in HBM until somebody reads them, and then equal the oracle's bit for bit."""
+    pts = D.bumpy_sphere(20000, 21)
+    pcd, center, scale = normalize_point_cloud(P.PointCloud(pts))
+    assert pcd._h["points"] is None and "points" in pcd._d      # edited on the device, not copied back
+    proc = pcd.voxel_down_sample(0.01)
+    proc.estimate_normals(P.KDTreeSearchParamKNN(16))
+    assert proc._h["points"] is None and proc._h["normals"] is None
+    ref, _, _ = oracle.normalize(pts)
+    vp, _, _ = oracle.voxel_downsample(ref, 0.01)
+    assert len(proc) == len(vp) and np.array_equal(np.asarray(proc.points), vp)
+    assert np.abs(np.asarray(proc.normals) - oracle.normals(vp, 16)).max() < 1e-6
+    # the outlier chain of filter_pcd
+    noisy = np.concatenate([pts, np.random.default_rng(3).random((200, 3)) * 2.0]).astype(np.float32).astype(np.float64)
+    cl = P.PointCloud(noisy)
+    a, ia = cl.remove_statistical_outlier(30, 3.0)
+    b, ib = a.remove_radius_outlier(4, 0.05)
+    assert a._h["points"] is None and b._h["points"] is None    # gathered on the device
+    ka, _, _ = oracle.sor(noisy, 30, 3.0)
+    assert len(ia) == len(ka) and np.array_equal(np.asarray(ia), ka)
+    kb = np.nonzero(oracle.radius_count(noisy[ka], 0.05) > 4)[0]
+    assert np.array_equal(np.asarray(ib), kb) and np.array_equal(np.asarray(b.points), noisy[ka][kb])
+
+
+def test_select_by_index_on_the_device(hip):
+    """pc_gather_rows / pc_gather_rows_f32 behind select_by_index: points, normals and colors, fp32 and fp64."""
+    rng = np.random.default_rng(5)
+    for fp32 in (True, False):
+        pts = D.gaussian_clusters(5000, 22, fp32=fp32)
+        pcd = P.PointCloud(pts)
+        pcd.normals = rng.normal(size=pts.shape)
+        pcd.colors = rng.random(pts.shape)
+        pcd.get_axis_aligned_bounding_box()                      # (uploads the coordinates)
+        idx = rng.permutation(5000)[:1234]
+        sel = pcd.select_by_index(P.geometry.LazyIndices(hip, hip.upload(idx.astype(np.int32)), len(idx)))
+        assert sel._h["points"] is None
+        assert np.array_equal(np.asarray(sel.points), pts[idx])
+        assert np.array_equal(np.asarray(sel.normals), np.asarray(pcd.normals)[idx])
+        assert np.array_equal(np.asarray(sel.colors), np.asarray(pcd.colors)[idx])
+        inv = pcd.select_by_index(idx, invert=True)
+        assert len(inv) == 5000 - 1234
+
+
+def test_non_finite_coordinates_are_rejected(hip):
+    """A cloud with an infinite or all-NaN coordinate has no finite bounding box: the index build says so
+    instead of spinning or building a garbage grid."""
+    p = D.uniform_cube(1000, 23, fp32=False) if "fp32" in D.uniform_cube.__code__.co_varnames else D.uniform_cube(1000, 23)
+    bad = p.copy()
+    bad[7, 0] = np.inf
+    bad[9, 1] = -np.inf
+    with pytest.raises(RuntimeError, match="non-finite"):
+        hip.knn(bad, None, 4, -1.0, {})
+    allnan = np.full((100, 3), np.nan)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        hip.knn(allnan, None, 4, -1.0, {})
+    with pytest.raises(RuntimeError, match="non-finite"):
+        hip.voxel_downsample(bad, None, None, 0.1, {})

@@ -235,3 +235,50 @@ def test_registration_icp_recovers_motion(oracle_engine):
         P.registration_icp(source, bare, 0.2)
     far = P.registration_icp(P.PointCloud(np.asarray(source.points) + 100.0), target, 0.2, max_iteration=3)
     assert far.fitness == 0.0 and np.array_equal(far.transformation, np.eye(4)) and len(far.correspondence_set) == 0
+
+
+def test_app_core_exports_the_reference_names():
+    """reference app/Core/__init__.py:1-27 re-exports eight names; all resolve, the mesh ones forward."""
+    import point_cloud_processing_amd.app.Core as core
+
+    for name in ["normalize_point_cloud", "preprocess_point_cloud", "reconstruct_poisson", "reconstruct_bpa",
+                 "straighten_slab_sides", "fill_small_holes", "fill_all_holes", "remove_long_triangles"]:
+        assert callable(getattr(core, name)) and name in core.__all__
+    with pytest.raises(RuntimeError, match="mesh"):
+        core.fill_all_holes(None)
+
+
+def test_reconstruct_bpa_computes_radii_then_needs_open3d(oracle, capsys):
+    from point_cloud_processing_amd.app.Core import reconstruct_bpa
+
+    pts = D.bumpy_sphere(3000, 4)
+    try:
+        import open3d  # noqa: F401
+        pytest.skip("open3d is installed: the pivoting would run")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="Ball Pivoting"):
+        reconstruct_bpa(P.PointCloud(pts))
+    out = capsys.readouterr().out
+    base = 1.5 * oracle.nn_distance(pts).mean()
+    assert "[BPA] Estimating radii" in out and f"radii={[base, base * 2.0, base * 3.0]}" in out
+    with pytest.raises(RuntimeError, match="Ball Pivoting"):
+        reconstruct_bpa(P.PointCloud(pts), radii=[0.1, 0.2])  # given radii: no search, same ending
+
+
+def test_orientation_needs_one_normal_per_point():
+    """Open3D's HasNormals(): points reassigned after estimate_normals leave the cloud without normals."""
+    pcd = P.PointCloud(D.uniform_cube(500, 7))
+    pcd.estimate_normals(P.KDTreeSearchParamKNN(10))
+    pcd.points = D.uniform_cube(800, 8)
+    assert not pcd.has_normals()
+    with pytest.raises(RuntimeError, match="No normals"):
+        pcd.orient_normals_consistent_tangent_plane(10)
+
+
+def test_translate_to_absolute_position_moves_the_mean():
+    pts = D.gaussian_clusters(400, 9, fp32=False)
+    pcd = P.PointCloud(pts)
+    pcd.translate([1.0, 2.0, 3.0], relative=False)
+    np.testing.assert_allclose(np.asarray(pcd.points).mean(0), [1.0, 2.0, 3.0], atol=1e-12)
+    np.testing.assert_allclose(np.asarray(pcd.points), pts - pts.mean(0) + [1.0, 2.0, 3.0], atol=1e-12)
