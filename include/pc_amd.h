@@ -58,6 +58,11 @@ const char *pc_last_error(const pc_ctx *ctx);
 const char *pc_status_string(int status);
 int pc_abi_version(void);
 
+/* Host helper of the upload path (no device work): dst[i] = (float)src[i] for count values; returns 1 when
+ * every value is exactly representable as fp32 (Open3D holds fp64, but clouds loaded from LAS / E57 files were
+ * fp32 once, reference app/Infrastructure/pointcloud_io.py:65-72: those can live in HBM as fp32), else 0. */
+int pc_host_to_f32_exact(const double *src, int64_t count, float *dst);
+
 /* ---- bounding box / rigid edits ------------------------------------------------------------
  * Replaces PointCloud.get_axis_aligned_bounding_box / translate / scale as used by
  * reference app/Core/pointcloud_preprocess.py:45-53 and :104-105. */
@@ -126,6 +131,33 @@ int pc_sor_avg(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end,
 int pc_knn_fused(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
                  int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, double *out_avg_dev,
                  double *out_normals_dev, const double *prior_dev, void *stream);
+/* pc_knn_fused for one rank of a multi-GPU job (queries sharded by sorted position over a replicated index): the
+ * same search for sorted positions [s_begin, s_end), but every output has s_end - s_begin rows, row s - s_begin for
+ * sorted position s, instead of n rows at the original index (100 M points x k = 32 would be 38 GB of rows per
+ * rank).  out_owned_dev (may be NULL) receives the original index of every row.  No prior normals. */
+int pc_knn_fused_compact(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
+                         int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, double *out_avg_dev,
+                         double *out_normals_dev, int32_t *out_owned_dev, void *stream);
+
+/* The sums behind the statistical filter's mean and standard deviation as a tree that is the same for any
+ * number of ranks: one partial per chunk of PC_SOR_CHUNK consecutive sorted positions, then one fixed pass over
+ * the partials in chunk order.  pc_sor_chunk_sums writes the partials (2 doubles per chunk: what = 0: sum of
+ * avg > 0 and number of avg >= 0; what = 1: sum over avg > 0 of (avg - mean)^2, and 0) of the chunks that make up
+ * [s_begin, s_end), which must begin at a chunk boundary and end at one or at n.  avg_dev: compact != 0: rows
+ * s - s_begin (pc_knn_fused_compact); else rows at the original index (pc_sor_avg).  partials_dev holds
+ * 2 * pc_sor_chunks(n) doubles; ranks of a multi-GPU job zero it, fill their own chunks and add the arrays
+ * elementwise (x + 0 is exact), then every rank calls pc_sor_chunk_finish on the same array: out[0], out[1]. */
+#define PC_SOR_CHUNK 4096
+int64_t pc_sor_chunks(int64_t n);
+int pc_sor_chunk_sums(pc_ctx *ctx, const pc_grid *grid, const double *avg_dev, int compact, int64_t s_begin, int64_t s_end,
+                      int what, double mean, double *partials_dev, void *stream);
+int pc_sor_chunk_finish(pc_ctx *ctx, const double *partials_dev, int64_t nchunks, double out[2], void *stream);
+/* mask[owned[i]] = avg[i] > 0 && avg[i] < threshold for the m compact rows of a rank (mask: n bytes, zeroed by the
+ * caller, added elementwise over the ranks); pc_mask_select: ascending indices of the non-zero bytes. */
+int pc_sor_mask_scatter(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, double threshold,
+                        uint8_t *mask_dev, void *stream);
+int pc_mask_select(pc_ctx *ctx, const uint8_t *mask_dev, int64_t n, int32_t *out_kept_dev, int64_t *n_kept, void *stream);
+
 /* Deterministic partial sums over avg[0..n): *sum_pos = sum of avg > 0, *n_valid = #(avg >= 0). */
 int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, int64_t *n_valid, void *stream);
 /* *sq = sum over avg > 0 of (avg - mean)^2. */
@@ -172,6 +204,9 @@ int pc_nn_distance(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_
 int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
                    void *stream);
 
+/* The inverse: dst[idx[i]] = src[i] (a rank's compact rows put back at their original indices; idx distinct). */
+int pc_scatter_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
+                    void *stream);
 /* The same for rows of 3 floats (clouds kept as fp32 because every coordinate is fp32-representable). */
 int pc_gather_rows_f32(pc_ctx *ctx, const float *src_dev, const int32_t *idx_dev, int64_t m, float *dst_dev,
                        void *stream);

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("PC_AMD_LIB") or os.path.join(_HERE, "libpc_amd.so")  
 
 PC_F32, PC_F64 = 0, 1
 PC_MAX_K = 64
+PC_SOR_CHUNK = 4096
 PC_SOR_SELECT_STATIC_MAX_N = 4 * 1024 * 1024
 
 # every symbol include/pc_amd.h declares: (name, restype, argtypes)
@@ -25,6 +26,7 @@ SYMBOLS = [
     ("pc_last_error", C.c_char_p, [_vp]),
     ("pc_status_string", C.c_char_p, [_i32]),
     ("pc_abi_version", _i32, []),
+    ("pc_host_to_f32_exact", _i32, [_vp, _i64, _vp]),
     ("pc_bbox", _i32, [_vp, _vp, _i32, _i64, _pd, _pd, _vp]),
     ("pc_center", _i32, [_vp, _vp, _i32, _i64, _pd, _vp]),
     ("pc_affine", _i32, [_vp, _vp, _i64, _pd, _i32, _dbl, _pd, _vp]),
@@ -39,6 +41,12 @@ SYMBOLS = [
     ("pc_knn_range", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp]),
     ("pc_sor_avg", _i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     ("pc_knn_fused", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("pc_knn_fused_compact", _i32, [_vp, _vp, _i64, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("pc_sor_chunks", _i64, [_i64]),
+    ("pc_sor_chunk_sums", _i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _dbl, _vp, _vp]),
+    ("pc_sor_chunk_finish", _i32, [_vp, _vp, _i64, _pd, _vp]),
+    ("pc_sor_mask_scatter", _i32, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp]),
+    ("pc_mask_select", _i32, [_vp, _vp, _i64, _vp, _pi64, _vp]),
     ("pc_sor_sum", _i32, [_vp, _vp, _i64, _pd, _pi64, _vp]),
     ("pc_sor_sqsum", _i32, [_vp, _vp, _i64, _dbl, _pd, _vp]),
     ("pc_sor_select", _i32, [_vp, _vp, _i64, _dbl, _vp, _vp, _pi64, _vp]),
@@ -47,6 +55,7 @@ SYMBOLS = [
     ("pc_radius_count", _i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _dbl, _vp, _vp]),
     ("pc_nn_distance", _i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     ("pc_gather_rows", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    ("pc_scatter_rows", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     ("pc_gather_rows_f32", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     ("pc_count_select", _i32, [_vp, _vp, _i64, _i32, _vp, _vp, _pi64, _vp]),
     ("pc_orient_normals", _i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),

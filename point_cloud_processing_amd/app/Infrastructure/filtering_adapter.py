@@ -49,18 +49,30 @@ def _estimate_nn_median(pcd: PointCloud, sample: int = 20000) -> float:
 
     Like the reference, the subset of a cloud with more than ``sample`` points comes from
     NumPy's global, unseeded generator, so it differs from run to run."""
-    pts = np.asarray(pcd.points)
-    if pts.shape[0] < 10:
+    n = len(pcd)
+    if n < 10:
         return 0.0
-    if pts.shape[0] > sample:
-        idx = np.random.choice(pts.shape[0], size=sample, replace=False)
-        p = PointCloud(pts[idx])
+    if n > sample:
+        p = pcd.select_by_index(_random_subset(n, sample))
     else:
         p = pcd
     d = np.asarray(p.compute_nearest_neighbor_distance(), dtype=np.float64)
     if d.size == 0:
         return 0.0
     return float(np.median(d))
+
+
+def _random_subset(n: int, size: int) -> np.ndarray:
+    """``size`` distinct indices below ``n``, uniformly at random, from NumPy's global generator like the
+    reference's ``np.random.choice(n, size, replace=False)`` (:43) -- drawn by rejecting repeats, which costs
+    O(size) where ``choice`` shuffles all ``n`` indices (7 ms of a 1 M-point filter call)."""
+    got = np.zeros(0, dtype=np.int64)
+    while len(got) < size:
+        draw = np.random.randint(0, n, size=2 * (size - len(got)) + 16)
+        both = np.concatenate([got, draw])
+        _, first = np.unique(both, return_index=True)
+        got = both[np.sort(first)][:size]  # (first occurrences, in drawing order)
+    return got
 
 
 class _Attempt:

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "pc_common.h"
 
@@ -501,6 +502,13 @@ __global__ __launch_bounds__(256) void k_gather_rows(const T *__restrict__ src, 
     dst[i] = src[3 * (size_t)idx[i / 3] + (i % 3)];
 }
 
+__global__ __launch_bounds__(256) void k_scatter_rows(const double *__restrict__ src, const int32_t *__restrict__ idx,
+                                                       int64_t m3, double *__restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m3) return;
+    dst[3 * (size_t)idx[i / 3] + (i % 3)] = src[i];
+}
+
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 int bits_for(uint64_t v) {
@@ -566,6 +574,32 @@ int pc_bbox(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_m
         return pc_fail(ctx, PC_BAD_ARG, "pc_bbox");
     PC_HIP(hipSetDevice(ctx->device));
     return bbox_impl(ctx, xyz_dev, dtype, n, out_min, out_max, (hipStream_t)stream);
+}
+
+int pc_host_to_f32_exact(const double *src, int64_t count, float *dst) {
+    // host helper of the upload path: dst = (float)src, returns 1 when every value survived the narrowing
+    // unchanged (the cloud can then live in HBM as fp32 without losing anything), 0 otherwise
+    if (count <= 0) return 1;
+    if (!src || !dst) return 0;
+    const int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, count / (1 << 18)));
+    std::vector<int> exact((size_t)nt, 1);
+    auto work = [&](int t) {
+        const int64_t b = count * t / nt, e = count * (t + 1) / nt;
+        int ok = 1;
+        for (int64_t i = b; i < e; i++) {
+            const float f = (float)src[i];
+            dst[i] = f;
+            ok &= ((double)f == src[i]) ? 1 : 0;  // (NaN compares unequal: such clouds stay fp64)
+        }
+        exact[(size_t)t] = ok;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    int ok = 1;
+    for (int v : exact) ok &= v;
+    return ok;
 }
 
 int pc_center(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double out_center[3], void *stream) {
@@ -1105,6 +1139,18 @@ int pc_gather_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, i
     PC_HIP(hipSetDevice(ctx->device));
     if (m == 0) return PC_OK;
     hipLaunchKernelGGL(k_gather_rows<double>, dim3(blocks_for(3 * m, 256)), dim3(256), 0, (hipStream_t)stream, src_dev,
+                       idx_dev, 3 * m, dst_dev);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_scatter_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, int64_t m, double *dst_dev,
+                    void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || m < 0 || (m > 0 && (!src_dev || !idx_dev || !dst_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_scatter_rows");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (m == 0) return PC_OK;
+    hipLaunchKernelGGL(k_scatter_rows, dim3(blocks_for(3 * m, 256)), dim3(256), 0, (hipStream_t)stream, src_dev,
                        idx_dev, 3 * m, dst_dev);
     PC_HIP(hipGetLastError());
     return PC_OK;

@@ -271,6 +271,59 @@ __global__ __launch_bounds__(256) void k_count_flags(const int32_t *__restrict__
     if (i < n) flags[i] = cnt[i] > nb ? 1 : 0;
 }
 
+// ---- the statistical filter's sums as a tree that does not depend on how the cloud is shared out -------
+// One partial per chunk of PC_SOR_CHUNK consecutive SORTED positions (a block per chunk, fixed tree inside),
+// then one wave over the partials in chunk order.  A rank of a multi-GPU job fills the partials of its own
+// chunks; elementwise addition with the other ranks' zeros is exact, so every rank finishes the same array.
+template <int WHAT>
+__global__ __launch_bounds__(256) void k_sor_chunk_sums(const double *__restrict__ avg, const int32_t *__restrict__ perm,
+                                                         int64_t avg_base, int64_t s_end, int64_t chunk0, double mean,
+                                                         double *__restrict__ part) {
+    const int64_t c = chunk0 + blockIdx.x;
+    const int64_t b = c * PC_SOR_CHUNK, e = b + PC_SOR_CHUNK < s_end ? b + PC_SOR_CHUNK : s_end;
+    double s = 0.0, cn = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+        // the value of sorted position i: compact rows (position - avg_base) or rows at the original index
+        const double v = perm ? avg[perm[i]] : avg[i - avg_base];
+        if (WHAT == 0) {
+            if (v > 0) s += v;
+            if (v >= 0) cn += 1.0;
+        } else {
+            if (v > 0) s += (v - mean) * (v - mean);
+        }
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = cn;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * c] = red[0][0];
+        part[2 * c + 1] = red[1][0];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_slots(const int32_t *__restrict__ perm, int64_t s_begin, int64_t s_end,
+                                                     int32_t *__restrict__ slot) {
+    const int64_t s = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < s_end) slot[perm[s]] = (int32_t)(s - s_begin);
+}
+
+__global__ __launch_bounds__(256) void k_mask_scatter(const double *__restrict__ avg, const int32_t *__restrict__ owned,
+                                                       int64_t m, double thr, uint8_t *__restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        const double v = avg[i];
+        mask[owned[i]] = (v > 0 && v < thr) ? 1 : 0;
+    }
+}
+
 int sor_reduce(pc_ctx *ctx, int what, const double *avg, int64_t n, double mean, double out[2], hipStream_t st) {
     out[0] = out[1] = 0.0;
     if (n <= 0) return PC_OK;
@@ -418,6 +471,102 @@ int pc_sor_select(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshol
     hipLaunchKernelGGL(k_sor_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, avg_dev, n, threshold, flags);
     PC_HIP(hipGetLastError());
     return pc_compact_flags(ctx, flags, n, out_kept_dev, n_kept, st);
+}
+
+int pc_knn_fused_compact(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int64_t s_end, int k, double radius,
+                         int32_t *out_idx_dev, void *out_d2_dev, int d2_dtype, int32_t *out_cnt_dev, double *out_avg_dev,
+                         double *out_normals_dev, int32_t *out_owned_dev, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || !grid || k < 1 || k > PC_MAX_K || !range_ok(grid, s_begin, s_end))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_knn_fused_compact");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t m = s_end - s_begin;
+    if (m == 0) return PC_OK;
+    // original index -> output row, for the queries of the range (other entries are never read)
+    Scratch slot(ctx, sizeof(int32_t) * (size_t)grid->n);
+    if (!slot.ok()) return pc_fail(ctx, PC_NOMEM, "output rows");
+    hipLaunchKernelGGL(k_fill_slots, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, grid->perm, s_begin, s_end,
+                       slot.as<int32_t>());
+    if (out_owned_dev)
+        PC_HIP(hipMemcpyAsync(out_owned_dev, grid->perm + s_begin, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToDevice, st));
+    ScanArgs A = base_args(grid);
+    A.s_begin = s_begin;
+    A.nq = m;
+    A.k = k;
+    A.radius2 = radius >= 0 ? radius * radius : -1.0;
+    A.out_idx = out_idx_dev;
+    A.out_d2 = out_d2_dev;
+    A.d2_f64 = d2_dtype == PC_F64;
+    A.out_cnt = out_cnt_dev;
+    A.out_f64 = out_avg_dev;
+    A.out_nrm = out_normals_dev;
+    A.out_slot = slot.as<int32_t>();
+    if (!out_avg_dev && !out_normals_dev) return launch_scan<M_KNN>(ctx, grid, grid->dtype, A, st);  // rows only
+    return launch_scan<M_ALL>(ctx, grid, grid->dtype, A, st);
+}
+
+int64_t pc_sor_chunks(int64_t n) { return n > 0 ? (n + PC_SOR_CHUNK - 1) / PC_SOR_CHUNK : 0; }
+
+int pc_sor_chunk_sums(pc_ctx *ctx, const pc_grid *grid, const double *avg_dev, int compact, int64_t s_begin, int64_t s_end,
+                      int what, double mean, double *partials_dev, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || !grid || !range_ok(grid, s_begin, s_end) || (s_end > s_begin && (!avg_dev || !partials_dev)) ||
+        s_begin % PC_SOR_CHUNK != 0 || (s_end % PC_SOR_CHUNK != 0 && s_end != grid->n) || (what != 0 && what != 1))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_sor_chunk_sums: the range must consist of whole chunks");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (s_end == s_begin) return PC_OK;
+    const int64_t c0 = s_begin / PC_SOR_CHUNK, c1 = (s_end + PC_SOR_CHUNK - 1) / PC_SOR_CHUNK;
+    const int32_t *perm = compact ? nullptr : grid->perm;
+    if (what == 0)
+        hipLaunchKernelGGL(k_sor_chunk_sums<0>, dim3((unsigned)(c1 - c0)), dim3(256), 0, (hipStream_t)stream, avg_dev, perm,
+                           s_begin, s_end, c0, mean, partials_dev);
+    else
+        hipLaunchKernelGGL(k_sor_chunk_sums<1>, dim3((unsigned)(c1 - c0)), dim3(256), 0, (hipStream_t)stream, avg_dev, perm,
+                           s_begin, s_end, c0, mean, partials_dev);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_sor_chunk_finish(pc_ctx *ctx, const double *partials_dev, int64_t nchunks, double out[2], void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || nchunks < 0 || nchunks > INT32_MAX || (nchunks > 0 && !partials_dev) || !out)
+        return pc_fail(ctx, PC_BAD_ARG, "pc_sor_chunk_finish");
+    PC_HIP(hipSetDevice(ctx->device));
+    out[0] = out[1] = 0.0;
+    if (nchunks == 0) return PC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch res(ctx, 256);
+    if (!res.ok()) return pc_fail(ctx, PC_NOMEM, "reduction scratch");
+    hipLaunchKernelGGL(k_sor_reduce_final, dim3(1), dim3(64), 0, st, partials_dev, (int)nchunks, res.as<double>());
+    PC_HIP(hipGetLastError());
+    double *hp = reinterpret_cast<double *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(hp, res.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    out[0] = hp[0];
+    out[1] = hp[1];
+    return PC_OK;
+}
+
+int pc_sor_mask_scatter(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, double threshold,
+                        uint8_t *mask_dev, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || m < 0 || (m > 0 && (!avg_dev || !owned_dev || !mask_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_mask_scatter");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (m == 0) return PC_OK;
+    hipLaunchKernelGGL(k_mask_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, avg_dev,
+                       owned_dev, m, threshold, mask_dev);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+int pc_mask_select(pc_ctx *ctx, const uint8_t *mask_dev, int64_t n, int32_t *out_kept_dev, int64_t *n_kept, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || n < 0 || (n > 0 && !mask_dev) || !n_kept) return pc_fail(ctx, PC_BAD_ARG, "pc_mask_select");
+    PC_HIP(hipSetDevice(ctx->device));
+    *n_kept = 0;
+    if (n == 0) return PC_OK;
+    return pc_compact_flags(ctx, mask_dev, n, out_kept_dev, n_kept, (hipStream_t)stream);
 }
 
 int pc_count_select(pc_ctx *ctx, const int32_t *cnt_dev, int64_t n, int32_t nb_points, uint8_t *out_mask_dev,

@@ -56,6 +56,9 @@ struct ScanArgs {
     double *out_f64;        // SOR avg / NN distance / normals
     double *out_nrm;        // normals of the fused mode (M_ALL), where out_f64 is the SOR average
     const double *prior;    // normals only
+    // compact outputs (query shards): row of the outputs that original index i is written to, or NULL: row i.
+    // (prior normals are not supported together with it: they are indexed by the original index.)
+    const int32_t *out_slot;
     // optional explicit list of sorted positions to answer (the exact re-run of queries that
     // the tile kernel could not certify); *qcount entries of qlist
     const int32_t *qlist;
@@ -327,6 +330,7 @@ __device__ inline void emit_normal(const ScanArgs &A, int64_t out_row, int cnt, 
 template <int MODE, bool ONLY_NORMALS = false, typename NB>
 __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, NB nb) {
     const int k = A.k;
+    if (A.out_slot) out_row = A.out_slot[out_row];
     if (!ONLY_NORMALS && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
         for (int s = 0; s < k; s++) {
             int32_t id = -1;

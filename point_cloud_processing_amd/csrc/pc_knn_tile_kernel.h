@@ -715,8 +715,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         // Rows and mean distance straight from the sorted registers (no second look at the candidates);
         // the long lists of k > 20 keep fewer registers alive by going through the generic consumer.
         constexpr bool DIRECT = KS <= 22;
+        const int64_t orow = A.out_slot ? (int64_t)A.out_slot[qid] : (int64_t)qid;  // row of the outputs
         if (DIRECT && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
-            const int64_t row = (int64_t)qid * k;
+            const int64_t row = orow * k;
             if ((k & 3) == 0) {  // (uniform) rows of 16-byte groups: vector stores
 #pragma unroll
                 for (int s = 0; s + 3 < KS; s += 4) {
@@ -759,7 +760,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                     }
                 }
             }
-            if (A.out_cnt) A.out_cnt[qid] = cnt;
+            if (A.out_cnt) A.out_cnt[orow] = cnt;
         }
         if (DIRECT && MODE == M_KNN) continue;
         if (DIRECT && (MODE == M_SOR || (MODE == M_ALL && A.out_f64))) {
@@ -768,11 +769,11 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
 #pragma unroll
             for (int s = 0; s < KS; s++)
                 if (s < cnt) sum += sqrt(dd[s]);
-            A.out_f64[qid] = cnt > 0 ? sum / (double)cnt : -1.0;
+            A.out_f64[orow] = cnt > 0 ? sum / (double)cnt : -1.0;
             if (MODE == M_SOR) continue;
         }
         if (MODE == M_NNDIST) {
-            A.out_f64[qid] = cnt > 1 ? sqrt(dd[1]) : 0.0;
+            A.out_f64[orow] = cnt > 1 ? sqrt(dd[1]) : 0.0;
             continue;
         }
         if (DIRECT && (MODE == M_NORMALS || MODE == M_ALL)) {
@@ -791,7 +792,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                         }
                     }
                 }
-                emit_normal<MODE>(A, (int64_t)qid, cnt, cu);
+                emit_normal<MODE>(A, orow, cnt, cu);
             }
             continue;
         }

@@ -1,14 +1,20 @@
 """Query sharding across the GPUs of one node (one process per GPU, torch.distributed).
 
 Layout: the cloud and its spatial index are replicated on every rank (10 M points are 160 MB
-of records, 100 M are 1.6 GB: small against 288 GB of HBM); rank r answers the queries at
-sorted positions [r*n/W, (r+1)*n/W) of the index, a spatially coherent, equally sized slice.
-kNN rows, normals and radius counts need no exchange at all.  The statistical outlier filter
-has one real exchange step: its global mean and standard deviation.  Each rank contributes
-(sum, count) and then the squared-deviation sum of its slice through a tiny all-gather
-(RCCL over xGMI when the backend is "nccl"), every rank adds the partials in rank order (so
-all ranks hold bit-identical statistics), and the kept indices are exchanged with one padded
-all-gather.  Nothing else crosses GPUs.
+of records, 100 M are 1.6 GB: small against 288 GB of HBM); rank r answers the queries of a
+contiguous slice of the index's sorted positions -- spatially coherent, equally sized, cut at
+multiples of the reduction chunk -- into outputs of ITS OWN size (rows in slice order plus the
+original index of every row).  kNN rows, normals and radius counts need no exchange at all.
+The statistical outlier filter has one real exchange step, its global mean and standard
+deviation: every rank fills the per-chunk partial sums of its own slice into a zeroed array, the
+arrays are added elementwise (RCCL all-reduce over xGMI when the backend is "nccl"; adding the
+other ranks' zeros is exact) and every rank finishes the same array with the same fixed tree, so
+the statistics carry the same bits for 1, 2, 4 or 8 ranks.  The kept mask is exchanged the same
+way (n bytes).  Nothing else crosses GPUs, and nothing visits the host but a few scalars.
+
+Each algorithm is written once, as a generator that yields the arrays it wants summed over the
+ranks: ``run`` drives it with ``dist.all_reduce``; ``run_emulated`` drives the generators of all
+ranks of a pretended world inside one process (tests on one GPU).
 """
 from __future__ import annotations
 
@@ -18,6 +24,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+SOR_CHUNK = 4096  # sorted positions per partial sum (PC_SOR_CHUNK of the C ABI)
+
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Half-open slice of ``n`` units owned by ``rank``: sizes differ by at most one."""
@@ -26,85 +34,125 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return b, b + base + (1 if rank < rem else 0)
 
 
-def _device(group=None) -> torch.device:
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
+def shard_positions(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Slice of the ``n`` sorted positions owned by ``rank``: whole reduction chunks, dealt evenly."""
+    chunks = (n + SOR_CHUNK - 1) // SOR_CHUNK
+    cb, ce = shard_range(chunks, rank, world)
+    return min(cb * SOR_CHUNK, n), min(ce * SOR_CHUNK, n)
 
 
-def all_gather_f64(values, group=None) -> np.ndarray:
-    """All-gather a few float64 scalars per rank -> array [world, len(values)] (rank order)."""
-    world = dist.get_world_size(group)
-    t = torch.tensor(list(values), dtype=torch.float64, device=_device(group))
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    return torch.stack(out).cpu().numpy()
+# ---- drivers -------------------------------------------------------------------------------------
+def _as_tensor(x):
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(x)  # (shares the array's memory)
 
 
-def all_gather_varlen(arr: np.ndarray, group=None) -> np.ndarray:
-    """Concatenate 1-D int64 arrays of different lengths from all ranks, in rank order."""
-    world = dist.get_world_size(group)
-    dev = _device(group)
-    n = torch.tensor([len(arr)], dtype=torch.int64, device=dev)
-    sizes = [torch.empty_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(sizes) if sizes else 0
-    buf = torch.zeros(max(m, 1), dtype=torch.int64, device=dev)
-    if len(arr):
-        buf[: len(arr)] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    return np.concatenate([o[:s].cpu().numpy() for o, s in zip(out, sizes)]) if sizes else np.zeros(0, np.int64)
+def run(gen, group=None):
+    """Drive one rank's generator: every yielded array is summed over the ranks of ``group``, in place
+    (a process without a process group is a world of one: nothing to add)."""
+    alone = not (dist.is_available() and dist.is_initialized())
+    try:
+        x = next(gen)
+        while True:
+            if not alone:
+                dist.all_reduce(_as_tensor(x), op=dist.ReduceOp.SUM, group=group)
+            x = gen.send(x)
+    except StopIteration as stop:
+        return stop.value
 
 
-def sor_sharded(engine, pts: np.ndarray, k: int, std_ratio: float, cache: Optional[dict] = None, group=None):
-    """Statistical outlier removal with the queries sharded over the ranks of ``group``.
+def run_emulated(make_gen, world: int):
+    """The same algorithm for ``world`` pretended ranks in this process: ``make_gen(rank)`` per rank, the
+    yielded arrays added in rank order.  Returns the list of the ranks' results."""
+    gens = [make_gen(r) for r in range(world)]
+    results = [None] * world
+    xs = []
+    for r, g in enumerate(gens):
+        try:
+            xs.append(next(g))
+        except StopIteration as stop:
+            results[r] = stop.value
+            xs.append(None)
+    while any(x is not None for x in xs):
+        ts = [_as_tensor(x) for x in xs]
+        total = ts[0].clone()
+        for t in ts[1:]:
+            total += t
+        nxt = []
+        for r, g in enumerate(gens):
+            ts[r].copy_(total)
+            try:
+                nxt.append(g.send(xs[r]))
+            except StopIteration as stop:
+                results[r] = stop.value
+                nxt.append(None)
+        xs = nxt
+    return results
 
-    Returns ``(kept_indices, (mean, std, threshold, valid))``; identical on every rank and
-    equal to the single-GPU result (reference semantics: filtering_adapter.py:91).
-    """
-    cache = {} if cache is None else cache
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    owned, avg = engine.sor_avg_shard(pts, k, cache, rank, world)  # original indices, their averages
-    pos = avg > 0
-    part = all_gather_f64([float(avg[pos].sum()) if pos.any() else 0.0, float((avg >= 0).sum())], group)
-    total, valid = 0.0, 0
-    for r in range(world):  # fixed order -> the same bits on every rank
-        total += part[r, 0]
-        valid += int(part[r, 1])
+
+# ---- the algorithms ------------------------------------------------------------------------------
+def _filter_core(engine, pts, cache: dict, k: int, std_ratio: float, sh: dict, b: int, e: int):
+    """The exchange steps of the statistical filter, given a rank's mean distances ``sh["avg"]``."""
+    n = len(pts)
+    part = yield engine.chunk_sums(pts, cache, k, sh["avg"], b, e, 0, 0.0)
+    total, valid = engine.chunk_finish(part)
+    valid = int(valid)
     if valid == 0:
-        return np.zeros(0, dtype=np.int64), (0.0, 0.0, 0.0, 0)
+        return engine.no_indices(), (0.0, 0.0, 0.0, 0)
     mean = total / valid
-    dev = avg[pos] - mean
-    part = all_gather_f64([float((dev * dev).sum()) if pos.any() else 0.0], group)
-    sq = 0.0
-    for r in range(world):
-        sq += part[r, 0]
+    part = yield engine.chunk_sums(pts, cache, k, sh["avg"], b, e, 1, mean)
+    sq, _ = engine.chunk_finish(part)
     with np.errstate(divide="ignore", invalid="ignore"):
         std = float(np.sqrt(np.float64(sq) / np.float64(valid - 1)))
     thr = mean + std_ratio * std
-    kept_local = owned[pos & (avg < thr)]
-    kept = np.sort(all_gather_varlen(kept_local, group))
-    return kept, (mean, std, thr, valid)
+    mask = yield engine.mask_scatter(sh["avg"], sh["owned"], thr, n)
+    return engine.mask_select(mask), (mean, std, thr, valid)
 
 
-def normals_sharded(engine, pts: np.ndarray, k: int, radius: float, cache: Optional[dict] = None, group=None):
-    """PCA normals with the queries sharded; the (n, 3) result is all-gathered to every rank."""
+def sor_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int):
+    """Statistical outlier removal of one rank (reference semantics: filtering_adapter.py:91)."""
+    b, e = shard_positions(len(pts), rank, world)
+    sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_avg=True)
+    return (yield from _filter_core(engine, pts, cache, k, std_ratio, sh, b, e))
+
+
+def pipeline_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, **search_kw):
+    """kNN rows + statistical filter + normals from ONE search of the rank's slice: returns the slice's
+    outputs (rows, mean distances, normals, owned indices), the kept indices and the statistics."""
+    b, e = shard_positions(len(pts), rank, world)
+    sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_rows=True, want_avg=True, want_normals=True, **search_kw)
+    kept, stats = yield from _filter_core(engine, pts, cache, k, std_ratio, sh, b, e)
+    return sh, kept, stats
+
+
+def normals_steps(engine, pts, k: int, radius: float, cache: dict, rank: int, world: int):
+    """PCA normals of one rank's slice, then the (n, 3) result put together on every rank."""
+    n = len(pts)
+    b, e = shard_positions(n, rank, world)
+    sh = engine.shard_search(pts, cache, k, radius, b, e, want_normals=True)
+    full = yield engine.rows_scatter(sh["normals"], sh["owned"], n)
+    return full
+
+
+def sor_sharded(engine, pts, k: int, std_ratio: float, cache: Optional[dict] = None, group=None):
+    """Statistical outlier removal with the queries sharded over the ranks of ``group``.
+
+    Returns ``(kept_indices, (mean, std, threshold, valid))``: identical on every rank and, bit for bit, for
+    every number of ranks."""
     cache = {} if cache is None else cache
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    owned, nrm = engine.normals_shard(pts, k, radius, cache, rank, world)
-    idx = all_gather_varlen(owned, group)
-    flat = all_gather_varlen(nrm.reshape(-1).view(np.int64), group).view(np.float64).reshape(-1, 3)
-    out = np.empty((len(pts), 3), dtype=np.float64)
-    out[idx] = flat
-    return out
+    return run(sor_steps(engine, pts, k, std_ratio, cache, dist.get_rank(group), dist.get_world_size(group)), group)
 
 
-def knn_sharded(engine, pts: np.ndarray, k: int, radius: float = -1.0, cache: Optional[dict] = None, group=None):
-    """kNN rows of this rank's slice only: ``(owned_indices, idx, d2, cnt)``.  Nothing is
-    exchanged: full neighbour lists stay on the GPU that computed them."""
+def normals_sharded(engine, pts, k: int, radius: float, cache: Optional[dict] = None, group=None):
+    """PCA normals with the queries sharded; the (n, 3) result on every rank (an engine array)."""
     cache = {} if cache is None else cache
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    return engine.knn_shard(pts, k, radius, cache, rank, world)
+    return run(normals_steps(engine, pts, k, radius, cache, dist.get_rank(group), dist.get_world_size(group)), group)
+
+
+def knn_sharded(engine, pts, k: int, radius: float = -1.0, cache: Optional[dict] = None, group=None):
+    """kNN rows of this rank's slice only: a dict with ``owned`` (original index of every row), ``idx``,
+    ``d2``, ``cnt``, each with as many rows as the slice.  Nothing is exchanged: full neighbour lists stay on
+    the GPU that computed them."""
+    cache = {} if cache is None else cache
+    n = len(pts)
+    b, e = shard_positions(n, dist.get_rank(group), dist.get_world_size(group))
+    return engine.shard_search(pts, cache, k, radius, b, e, want_rows=True)

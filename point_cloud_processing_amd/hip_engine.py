@@ -145,8 +145,11 @@ class HipEngine:
             if isinstance(pts, torch.Tensor):
                 t = pts
             else:
-                p32 = pts.astype(np.float32)
-                t = self.upload(p32 if np.array_equal(p32.astype(np.float64), pts) else pts)
+                src = np.ascontiguousarray(pts, dtype=np.float64)
+                p32 = np.empty(src.shape, dtype=np.float32)
+                exact = self.lib.pc_host_to_f32_exact(src.ctypes.data_as(C.c_void_p), src.size,
+                                                      p32.ctypes.data_as(C.c_void_p))
+                t = self.upload(p32 if exact else src)
             cache["xyz"] = t
         return t
 
@@ -287,27 +290,40 @@ class HipEngine:
             cache[key] = avg
         return avg
 
-    def sor_stats(self, avg: torch.Tensor, std_ratio: float):
+    def sor_stats(self, avg: torch.Tensor, std_ratio: float, pts=None, cache=None, k=None):
+        """(mean, std, threshold, valid) of the per-point mean distances.  With the cloud given, the sums run
+        over chunks of the index's sorted positions: the tree a multi-GPU job uses, so one GPU and eight give
+        the same bits.  Without it: over the array as it lies (pc_sor_sum / pc_sor_sqsum)."""
         n = avg.numel()
-        s = C.c_double(0)
-        valid = C.c_int64(0)
-        self._check(self.lib.pc_sor_sum(self.ctx, _ptr(avg), n, C.byref(s), C.byref(valid), self.stream()),
-                    "pc_sor_sum")
-        if valid.value == 0:
-            return 0.0, 0.0, 0.0, 0
-        mean = s.value / valid.value
-        sq = C.c_double(0)
-        self._check(self.lib.pc_sor_sqsum(self.ctx, _ptr(avg), n, mean, C.byref(sq), self.stream()), "pc_sor_sqsum")
+        if pts is not None:
+            total, valid = self.chunk_finish(self.chunk_sums(pts, cache, k, avg, 0, n, 0, 0.0, compact=False))
+            valid = int(valid)
+            if valid == 0:
+                return 0.0, 0.0, 0.0, 0
+            mean = total / valid
+            sq, _ = self.chunk_finish(self.chunk_sums(pts, cache, k, avg, 0, n, 1, mean, compact=False))
+        else:
+            s = C.c_double(0)
+            nv = C.c_int64(0)
+            self._check(self.lib.pc_sor_sum(self.ctx, _ptr(avg), n, C.byref(s), C.byref(nv), self.stream()),
+                        "pc_sor_sum")
+            valid = nv.value
+            if valid == 0:
+                return 0.0, 0.0, 0.0, 0
+            mean = s.value / valid
+            q = C.c_double(0)
+            self._check(self.lib.pc_sor_sqsum(self.ctx, _ptr(avg), n, mean, C.byref(q), self.stream()), "pc_sor_sqsum")
+            sq = q.value
         with np.errstate(divide="ignore", invalid="ignore"):
-            std = float(np.sqrt(np.float64(sq.value) / np.float64(valid.value - 1)))
-        return mean, std, mean + std_ratio * std, valid.value
+            std = float(np.sqrt(np.float64(sq) / np.float64(valid - 1)))
+        return mean, std, mean + std_ratio * std, valid
 
     def sor_dev(self, pts, k, std_ratio, cache):
         """Kept indices of the statistical filter, still on the device (a LazyIndices)."""
         from .geometry import LazyIndices
 
         avg = self.sor_avg_dev(pts, k, cache)
-        mean, std, thr, valid = self.sor_stats(avg, std_ratio)
+        mean, std, thr, valid = self.sor_stats(avg, std_ratio, pts, cache, k)
         if valid == 0:
             return LazyIndices(self, self.empty((0,), torch.int32), 0)
         n = avg.numel()
@@ -358,41 +374,68 @@ class HipEngine:
             out[name] = dst
         return out
 
-    # -- sharded variants: rank r of W answers sorted positions [r*n/W, (r+1)*n/W) --------------------
-    def _owned(self, g: DeviceGrid, rank: int, world: int):
-        from .distributed import shard_range
-
-        b, e = shard_range(g.n, rank, world)
-        t = self.empty((max(e - b, 1),), torch.int32)
-        self._check(self.lib.pc_grid_perm_copy(self.ctx, g.h, b, e, _ptr(t), self.stream()), "pc_grid_perm_copy")
-        return b, e, t[: e - b].cpu().numpy().astype(np.int64)
-
-    def sor_avg_shard(self, pts, k, cache, rank, world):
+    # -- one rank of a multi-GPU job: queries = sorted positions [b, e) of the replicated index -------------
+    def shard_search(self, pts, cache, k, radius, b, e, want_rows=False, want_avg=False, want_normals=False,
+                     d2_dtype=torch.float64):
+        """One fused search over the slice; every output has e - b rows (row s - b for sorted position s) and
+        stays on the device.  ``owned``: the original index of every row."""
         g = self.grid(pts, cache, k)
-        b, e, owned = self._owned(g, rank, world)
-        avg = torch.full((len(pts),), -2.0, dtype=torch.float64, device=self.device)
-        self._check(self.lib.pc_sor_avg(self.ctx, g.h, b, e, int(k), _ptr(avg), self.stream()), "pc_sor_avg")
-        return owned, avg.cpu().numpy()[owned]
+        m = e - b
+        out = {"owned": self.empty((max(m, 1),), torch.int32)[:m]}
+        if want_rows:
+            out["idx"] = self.empty((m, k), torch.int32)
+            out["d2"] = self.empty((m, k), d2_dtype)
+            out["cnt"] = self.empty((m,), torch.int32)
+        if want_avg:
+            out["avg"] = self.empty((m,), torch.float64)
+        if want_normals:
+            out["normals"] = self.empty((m, 3), torch.float64)
+        self._check(self.lib.pc_knn_fused_compact(self.ctx, g.h, b, e, int(k), float(radius), _ptr(out.get("idx")),
+                                                  _ptr(out.get("d2")), self._dt(out["d2"]) if want_rows else _lib.PC_F64,
+                                                  _ptr(out.get("cnt")), _ptr(out.get("avg")), _ptr(out.get("normals")),
+                                                  _ptr(out["owned"]), self.stream()), "pc_knn_fused_compact")
+        return out
 
-    def normals_shard(self, pts, k, radius, cache, rank, world):
+    def chunk_sums(self, pts, cache, k, avg, b, e, what, mean, compact=True) -> torch.Tensor:
+        """Zeroed partial-sum array of the whole cloud with the chunks of [b, e) filled in."""
         g = self.grid(pts, cache, k)
-        b, e, owned = self._owned(g, rank, world)
-        out = torch.zeros((len(pts), 3), dtype=torch.float64, device=self.device)
-        self._check(self.lib.pc_normals(self.ctx, g.h, b, e, int(k), float(radius), None, _ptr(out), self.stream()),
-                    "pc_normals")
-        return owned, out.cpu().numpy()[owned]
+        part = torch.zeros((2 * int(self.lib.pc_sor_chunks(len(pts))),), dtype=torch.float64, device=self.device)
+        self._check(self.lib.pc_sor_chunk_sums(self.ctx, g.h, _ptr(avg), 1 if compact else 0, b, e, int(what), float(mean),
+                                               _ptr(part), self.stream()), "pc_sor_chunk_sums")
+        return part
 
-    def knn_shard(self, pts, k, radius, cache, rank, world):
-        g = self.grid(pts, cache, k)
-        b, e, owned = self._owned(g, rank, world)
-        n = len(pts)
-        idx = torch.full((n, k), -1, dtype=torch.int32, device=self.device)
-        d2 = torch.full((n, k), float("inf"), dtype=torch.float64, device=self.device)
-        cnt = torch.zeros((n,), dtype=torch.int32, device=self.device)
-        self._check(self.lib.pc_knn_range(self.ctx, g.h, b, e, int(k), float(radius), _ptr(idx), _ptr(d2),
-                                          _lib.PC_F64, _ptr(cnt), self.stream()), "pc_knn_range")
-        o = torch.from_numpy(owned).to(self.device)
-        return owned, idx[o].cpu().numpy(), d2[o].cpu().numpy(), cnt[o].cpu().numpy()
+    def chunk_finish(self, part: torch.Tensor):
+        out = (C.c_double * 2)()
+        self._check(self.lib.pc_sor_chunk_finish(self.ctx, _ptr(part), part.numel() // 2, out, self.stream()),
+                    "pc_sor_chunk_finish")
+        return float(out[0]), float(out[1])
+
+    def mask_scatter(self, avg, owned, thr, n) -> torch.Tensor:
+        mask = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.pc_sor_mask_scatter(self.ctx, _ptr(avg), _ptr(owned), avg.numel(), float(thr), _ptr(mask),
+                                                 self.stream()), "pc_sor_mask_scatter")
+        return mask
+
+    def mask_select(self, mask: torch.Tensor):
+        from .geometry import LazyIndices
+
+        n = mask.numel()
+        kept = self.empty((max(n, 1),), torch.int32)
+        nk = C.c_int64(0)
+        self._check(self.lib.pc_mask_select(self.ctx, _ptr(mask), n, _ptr(kept), C.byref(nk), self.stream()),
+                    "pc_mask_select")
+        return LazyIndices(self, kept[: nk.value], nk.value)
+
+    def no_indices(self):
+        from .geometry import LazyIndices
+
+        return LazyIndices(self, self.empty((0,), torch.int32), 0)
+
+    def rows_scatter(self, rows: torch.Tensor, owned: torch.Tensor, n: int) -> torch.Tensor:
+        full = torch.zeros((n, 3), dtype=torch.float64, device=self.device)
+        self._check(self.lib.pc_scatter_rows(self.ctx, _ptr(rows), _ptr(owned), owned.numel(), _ptr(full), self.stream()),
+                    "pc_scatter_rows")
+        return full
 
     def normals_dev(self, pts, k, radius, prior, cache) -> torch.Tensor:
         g = self.grid(pts, cache, k)

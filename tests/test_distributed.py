@@ -1,5 +1,6 @@
 """Multi-rank query sharding: world_size 2 and 3 over gloo on CPU (oracle engine), checked
-against the single-rank result.  The same code path runs over RCCL with the HIP engine."""
+against the one-rank run of the same code.  The same generators run over RCCL with the HIP engine
+(tests/test_gpu_configs.py drives them for several pretended world sizes on one GPU)."""
 import os
 import socket
 
@@ -17,6 +18,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _cloud():
+    # (more than two reduction chunks, so that every rank of 3 owns some)
+    pts = np.concatenate([D.bumpy_sphere(13000, 3), np.random.default_rng(4).random((177, 3)) * 0.3])
+    return pts.astype(np.float32).astype(np.float64)
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -26,42 +33,58 @@ def _worker(rank, world, port, out_dir):
         from point_cloud_processing_amd import distributed as PD
 
         eng = OracleEngine()
-        pts = np.concatenate([D.bumpy_sphere(6000, 3), np.random.default_rng(4).random((77, 3)) * 0.3])
-        pts = pts.astype(np.float32).astype(np.float64)
+        pts = _cloud()
         kept, stats = PD.sor_sharded(eng, pts, 20, 2.0)
         nrm = PD.normals_sharded(eng, pts, 30, 0.01)
-        owned, idx, d2, cnt = PD.knn_sharded(eng, pts, 8)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), kept=kept, stats=np.array(stats), nrm=nrm, owned=owned,
-                 idx=idx, d2=d2, cnt=cnt)
+        sh = PD.knn_sharded(eng, pts, 8)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), kept=np.asarray(kept), stats=np.array(stats), nrm=nrm,
+                 owned=sh["owned"], idx=sh["idx"], d2=sh["d2"], cnt=sh["cnt"])
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_matches_single_rank(oracle, tmp_path, world):
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd import distributed as PD
+
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    pts = np.concatenate([D.bumpy_sphere(6000, 3), np.random.default_rng(4).random((77, 3)) * 0.3])
-    pts = pts.astype(np.float32).astype(np.float64)
+    pts = _cloud()
+    # one rank, same code: the statistics must carry the same bits for every number of ranks
+    (kept1, stats1), = PD.run_emulated(lambda r: PD.sor_steps(OracleEngine(), pts, 20, 2.0, {}, r, 1), 1)
     rkept, ravg, rstats = oracle.sor(pts, 20, 2.0)
+    assert np.array_equal(kept1, rkept)
+    np.testing.assert_allclose(stats1[:3], rstats[:3], rtol=1e-13)  # (the oracle's own sum is another tree)
     rn = oracle.normals(pts, 30, 0.01)
     ridx, rd2, rcnt = oracle.knn(pts, None, 8)
     res = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     seen = np.zeros(len(pts), dtype=int)
     for r in res:
         assert np.array_equal(r["kept"], rkept)            # identical on every rank, equal to 1 rank
-        np.testing.assert_allclose(r["stats"][:3], rstats[:3], rtol=1e-13)
-        assert r["stats"][3] == rstats[3]
+        assert np.array_equal(r["stats"], np.array(stats1))  # bit-identical to the one-rank statistics
         assert np.array_equal(r["nrm"], rn)
         assert np.array_equal(r["idx"], ridx[r["owned"]]) and np.array_equal(r["d2"], rd2[r["owned"]])
+        assert len(r["owned"]) == len(r["idx"]) == len(r["cnt"])  # outputs of the shard's own size
         seen[r["owned"]] += 1
     assert (seen == 1).all()                               # the shards partition the queries
-    for r in res[1:]:
-        assert np.array_equal(r["stats"], res[0]["stats"])  # bit-identical statistics on all ranks
+
+
+def test_emulated_world_equals_real_world(oracle):
+    """run_emulated (all ranks in one process) gives what the real collective gives: same generators."""
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd import distributed as PD
+
+    pts = _cloud()
+    one = PD.run_emulated(lambda r: PD.sor_steps(OracleEngine(), pts, 20, 2.0, {}, r, 1), 1)[0]
+    for world in (2, 4, 8):
+        res = PD.run_emulated(lambda r: PD.sor_steps(OracleEngine(), pts, 20, 2.0, {}, r, world), world)
+        for kept, stats in res:
+            assert np.array_equal(kept, one[0]) and stats == one[1]
 
 
 def test_shard_range_partitions():
-    from point_cloud_processing_amd.distributed import shard_range
+    from point_cloud_processing_amd.distributed import SOR_CHUNK, shard_positions, shard_range
 
     for n in (0, 1, 7, 64, 1000003):
         for w in (1, 2, 3, 8):
@@ -69,3 +92,7 @@ def test_shard_range_partitions():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             assert max(e - b for b, e in cuts) - min(e - b for b, e in cuts) <= 1
+            pos = [shard_positions(n, r, w) for r in range(w)]
+            assert pos[0][0] == 0 and pos[-1][1] == n
+            assert all(pos[i][1] == pos[i + 1][0] for i in range(w - 1))
+            assert all(b % SOR_CHUNK == 0 for b, e in pos if e > b)

@@ -124,8 +124,13 @@ def test_mixed_first_pass_agrees(hip, oracle, monkeypatch, k):
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
     np.testing.assert_allclose(avg, np.sqrt(rd2).sum(1) / k, rtol=1e-13)
     seen = np.zeros(len(p), dtype=int)
+    from point_cloud_processing_amd.distributed import shard_positions
+
     for r in range(3):
-        owned, sidx, sd2, scnt = hip.knn_shard(p, k, -1.0, cache, r, 3)
-        assert np.array_equal(sidx, ridx[owned]) and np.array_equal(sd2, rd2[owned]) and np.array_equal(scnt, rcnt[owned])
+        b, e = shard_positions(len(p), r, 3)
+        sh = {n: v.cpu().numpy() for n, v in hip.shard_search(p, cache, k, -1.0, b, e, want_rows=True).items()}
+        owned = sh["owned"]
+        assert np.array_equal(sh["idx"], ridx[owned]) and np.array_equal(sh["d2"], rd2[owned])
+        assert np.array_equal(sh["cnt"], rcnt[owned])
         seen[owned] += 1
     assert (seen == 1).all()

@@ -166,7 +166,7 @@ def test_sor(hip, oracle, name, k, sr):
     rkept, ravg, rstats = oracle.sor(p, k, sr)
     avg = cache[("sor_avg", k)].cpu().numpy()
     np.testing.assert_allclose(avg, ravg, rtol=1e-13, atol=0)
-    mean, std, thr, valid = hip.sor_stats(cache[("sor_avg", k)], sr)
+    mean, std, thr, valid = hip.sor_stats(cache[("sor_avg", k)], sr, p, cache, k)
     assert valid == int(rstats[3])
     np.testing.assert_allclose([mean, std, thr], rstats[:3], rtol=1e-12)
     assert np.array_equal(kept, rkept)
@@ -285,7 +285,9 @@ def test_headline_10m_matches_oracle(hip, oracle):
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_query_shards_cover_and_agree(hip, oracle, world):
     """Each rank's slice of sorted positions, run one after the other on this GPU, reproduces the
-    single-GPU result exactly (what 2/4/8 ranks compute in parallel)."""
+    single-GPU result exactly (what 2/4/8 ranks compute in parallel), in outputs of the slice's own size."""
+    from point_cloud_processing_amd.distributed import shard_positions
+
     p = D.gaussian_clusters(30000, 77)
     cache = {}
     ravg = oracle.sor_avg(p, 16)
@@ -293,14 +295,44 @@ def test_query_shards_cover_and_agree(hip, oracle, world):
     ridx, rd2, rcnt = oracle.knn(p, None, 16)
     seen = np.zeros(len(p), dtype=int)
     for r in range(world):
-        owned, avg = hip.sor_avg_shard(p, 16, cache, r, world)
-        np.testing.assert_allclose(avg, ravg[owned], rtol=1e-13)
-        o2, nrm = hip.normals_shard(p, 16, -1.0, cache, r, world)
-        assert np.array_equal(o2, owned) and np.abs(nrm - rn[owned]).max() < 1e-6
-        o3, idx, d2, cnt = hip.knn_shard(p, 16, -1.0, cache, r, world)
-        assert np.array_equal(idx, ridx[owned]) and np.array_equal(d2, rd2[owned]) and np.array_equal(cnt, rcnt[owned])
+        b, e = shard_positions(len(p), r, world)
+        sh = {k: v.cpu().numpy() for k, v in hip.shard_search(p, cache, 16, -1.0, b, e, want_rows=True, want_avg=True,
+                                                             want_normals=True).items()}
+        owned = sh["owned"]
+        assert all(len(v) == e - b for v in sh.values())
+        np.testing.assert_allclose(sh["avg"], ravg[owned], rtol=1e-13)
+        assert np.abs(sh["normals"] - rn[owned]).max() < 1e-6
+        assert np.array_equal(sh["idx"], ridx[owned]) and np.array_equal(sh["d2"], rd2[owned])
+        assert np.array_equal(sh["cnt"], rcnt[owned])
         seen[owned] += 1
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("name", ["sphere", "clusters"])
+def test_sharded_filter_carries_the_same_bits_for_any_world(hip, oracle, name):
+    """The multi-GPU statistical filter and normals (distributed.sor_steps / normals_steps, the generators
+    that run over RCCL) for 1, 2, 3 and 8 pretended ranks on this GPU: kept indices, mean, standard deviation
+    and threshold are the same bits for every world size and equal the single-GPU engine call."""
+    from point_cloud_processing_amd import distributed as PD
+
+    p = (D.bumpy_sphere(40000, 88) if name == "sphere" else D.gaussian_clusters(40000, 89))
+    p = np.concatenate([p, np.random.default_rng(9).random((300, 3))]).astype(np.float32).astype(np.float64)
+    single = np.asarray(hip.sor(p, 20, 2.0, {}))
+    rkept, _, rstats = oracle.sor(p, 20, 2.0)
+    assert np.array_equal(single, rkept)
+    first = None
+    for world in (1, 2, 3, 8):
+        cache = {}
+        res = PD.run_emulated(lambda r: PD.sor_steps(hip, p, 20, 2.0, cache, r, world), world)
+        for kept, stats in res:
+            assert np.array_equal(np.asarray(kept), single)
+            first = first or stats
+            assert stats == first  # bit-identical (mean, std, threshold, valid)
+        np.testing.assert_allclose(first[:3], rstats[:3], rtol=1e-12)
+    nrm = PD.run_emulated(lambda r: PD.normals_steps(hip, p, 16, -1.0, {}, r, 3), 3)
+    one = hip.normals(p, 16, -1.0, None, {})
+    for x in nrm:
+        assert np.array_equal(x.cpu().numpy(), one)
 
 
 @pytest.mark.parametrize("case", ["all_duplicates", "collinear", "coplanar_lattice", "far_offset_fp64", "two_far_clusters",
