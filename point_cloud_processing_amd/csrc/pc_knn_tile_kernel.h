@@ -425,6 +425,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         // a model of the uniform 10 M cloud); what is left is inserted at the end.  `thr` lags behind
         // the list, which only lets a few keys too many through: the final list is the same KS
         // smallest keys either way.
+        uint32_t thr0 = KEY_INF;  // no key at or above it is ever wanted (set below, once the query's cells are known)
         uint32_t thr = KEY_INF;
 #ifdef PC_COUNT
         uint32_t n_steps = 0, n_rounds = 0, n_drains = 0, n_lock = 0;
@@ -453,7 +454,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             n_drains++;
 #endif
             wp = valid ? ra : col_a - 4u * PC_WAVE;
-            thr = min(L[KS - 1], KEY_INF);
+            thr = min(L[KS - 1], thr0);
         };
         int qc[3];
         {   // the cell along x by the expression that made the cell keys; along y and z it is the row's
@@ -470,6 +471,49 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             const uint32_t hq = x_half_of(qxd, gp, qc[0]);
             if (!hq && qc[0] + 1 <= gp.dim[0] - 1) trim = 1;
             if (hq && qc[0] - 1 >= 0) trim = -1;
+        }
+        // distance to the nearest face of the scanned cells, measured like the cell keys: in offsets from the
+        // grid origin (a face position added to a far origin would round at the origin's magnitude)
+        const double qv[3] = {qxd - gp.o[0], qyd - gp.o[1], qzd - gp.o[2]};
+        bool whole = true;
+        double dmin = INFINITY;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int nlo = max(qc[a] - 1, 0), nhi = min(qc[a] + 1, gp.dim[a] - 1);
+            if (nlo > 0) {
+                whole = false;
+                dmin = fmin(dmin, qv[a] - (double)nlo * gp.cell);
+            }
+            if (nhi < gp.dim[a] - 1) {
+                whole = false;
+                dmin = fmin(dmin, (double)(nhi + 1) * gp.cell - qv[a]);
+            }
+            if (a == 0 && trim != 0) {  // the half-cell left out begins in the middle of its cell
+                whole = false;
+                const double mid = ((double)(qc[0] + trim) + 0.5) * gp.cell;
+                dmin = fmin(dmin, trim > 0 ? mid - qv[0] : qv[0] - mid);
+            }
+        }
+        double bound = INFINITY;  // no unscanned point is closer than sqrt(bound)
+        if (!whole) {
+            const double b = dmin - eps;
+            bound = b > 0 ? b * b : 0.0;
+        }
+        // A candidate at or beyond that bound (or beyond the search radius) can never be one of the certified
+        // neighbours: the threshold starts there instead of at infinity, and a quarter fewer keys are parked
+        // (rounds of insertion per 64 queries 69 -> 54 in a model of the uniform 10 M cloud).  The margin of
+        // 0.1 % covers the truncation of the keys (2^-12), the fp32 measurement and, for fp64 grids, the rounded
+        // frame of the filter: what stays unlisted for this reason alone is farther than `bound`.
+        {
+            double seed = fmin(bound, r2lim >= 0.0 ? r2lim : INFINITY);
+            if (seed < INFINITY) {
+                if (TileRec<REC>::kRelative) {
+                    const double rs = sqrt(seed) + 4.76837158203125e-07 * bext;
+                    seed = rs * rs;
+                }
+                thr0 = min(KEY_INF, __float_as_uint((float)(seed * 1.001)) & ~ORD_MASK);
+            }
+            thr = thr0;
         }
         // the nine (start, length) pairs up front: two table entries each, all reads in flight at once.
         // Order: the query's own row, the four rows sharing a face with it, the four diagonal ones,
@@ -565,33 +609,6 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         if (!live) continue;
 
         // ---- stage 2: exact finish --------------------------------------------------------------------
-        // distance to the nearest face of the scanned cells, measured like the cell keys: in offsets from the
-        // grid origin (a face position added to a far origin would round at the origin's magnitude)
-        const double qv[3] = {qxd - gp.o[0], qyd - gp.o[1], qzd - gp.o[2]};
-        bool whole = true;
-        double dmin = INFINITY;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const int nlo = max(qc[a] - 1, 0), nhi = min(qc[a] + 1, gp.dim[a] - 1);
-            if (nlo > 0) {
-                whole = false;
-                dmin = fmin(dmin, qv[a] - (double)nlo * gp.cell);
-            }
-            if (nhi < gp.dim[a] - 1) {
-                whole = false;
-                dmin = fmin(dmin, (double)(nhi + 1) * gp.cell - qv[a]);
-            }
-            if (a == 0 && trim != 0) {  // the half-cell left out begins in the middle of its cell
-                whole = false;
-                const double mid = ((double)(qc[0] + trim) + 0.5) * gp.cell;
-                dmin = fmin(dmin, trim > 0 ? mid - qv[0] : qv[0] - mid);
-            }
-        }
-        double bound = INFINITY;  // no unscanned point is closer than sqrt(bound)
-        if (!whole) {
-            const double b = dmin - eps;
-            bound = b > 0 ? b * b : 0.0;
-        }
         // no unlisted candidate of the scanned cells is closer than sqrt(T * (1 - 2^-20))
         if (L[KS - 1] != KEY_EMPTY) {
             const double T = (double)__uint_as_float(L[KS - 1] & ~ORD_MASK);

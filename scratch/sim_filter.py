@@ -53,7 +53,7 @@ def segments(qi):
     return segs
 
 
-def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0):
+def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0, seed_reach=0.0):
     waves = wave_queries()
     sel = rng.choice(len(waves), size=min(nwaves, len(waves)), replace=False)
     tot_steps = tot_rounds = tot_drains = tot_parked = tot_cand = 0
@@ -61,6 +61,12 @@ def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0):
         qs = waves[wi]
         L = [[] for _ in qs]          # sorted lists (as python lists of d2)
         thr = [np.inf] * len(qs)
+        if seed_reach > 0:
+            for li, q in enumerate(qs):
+                x, y, z = pts[q] - cell[q]
+                rx = (x + 1.0, 1.5 - x) if half[q] == 0 else (x - 0.5 + 1.0, 2.0 - x)
+                reach = min(rx[0], rx[1], y + 1.0, 2.0 - y, z + 1.0, 2.0 - z) * seed_reach
+                thr[li] = reach * reach
         park = [[] for _ in qs]
         segs = [segments(q) for q in qs]
         if sort_segs == 1:   # own row first, the other eight by length, longest first
@@ -83,7 +89,7 @@ def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0):
                 if take:
                     L[li] = sorted(L[li] + take)[:KS]
                     if len(L[li]) == KS:
-                        thr[li] = L[li][-1]
+                        thr[li] = min(thr[li], L[li][-1])
 
         for seg in range(9):
             tmax = max(s[seg][1] for s in segs)
@@ -114,8 +120,8 @@ def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0):
 
 
 if __name__ == "__main__":
-    for args in [dict(policy="full"), dict(policy="partial", partial=8), dict(policy="partial", partial=8, sort_segs=1),
-                 dict(policy="partial", partial=8, sort_segs=2), dict(policy="partial", partial=8, sort_segs=3),
-                 dict(policy="full", sort_segs=1)]:
+    for args in [dict(policy="partial", partial=8), dict(policy="partial", partial=8, seed_reach=1.0),
+                 dict(policy="partial", partial=8, seed_reach=1.0, sort_segs=2), dict(policy="partial", partial=6, seed_reach=1.0),
+                 dict(policy="partial", partial=8, seed_reach=1.0, slots=12)]:
         rng = np.random.default_rng(1)
         print(args, run(**args))

@@ -282,3 +282,23 @@ def test_translate_to_absolute_position_moves_the_mean():
     pcd.translate([1.0, 2.0, 3.0], relative=False)
     np.testing.assert_allclose(np.asarray(pcd.points).mean(0), [1.0, 2.0, 3.0], atol=1e-12)
     np.testing.assert_allclose(np.asarray(pcd.points), pts - pts.mean(0) + [1.0, 2.0, 3.0], atol=1e-12)
+
+
+def test_loader_subsample_draws_the_reference_indices():
+    """reference app/Infrastructure/pointcloud_io.py:41-45, 56-59: blake2b(path) -> default_rng(seed) ->
+    choice(total, max_points, replace=False); the same numbers here, then a row gather."""
+    import hashlib
+    from point_cloud_processing_amd.app.Infrastructure.pointcloud_io import subsample_indices, subsample_point_cloud
+
+    path = "scans/site 7/cloud.laz"
+    seed = int.from_bytes(hashlib.blake2b(path.encode("utf-8"), digest_size=8).digest(), "little") & 0xFFFFFFFF
+    want = np.random.default_rng(seed).choice(5000, 1200, replace=False)
+    assert np.array_equal(subsample_indices(5000, 1200, path), want)
+    assert np.array_equal(subsample_indices(900, 1200, path), np.arange(900))
+    pts = D.uniform_cube(5000, 12)
+    pcd = P.PointCloud(pts)
+    pcd.colors = np.random.default_rng(1).random(pts.shape)
+    out = subsample_point_cloud(pcd, 1200, path)
+    assert np.array_equal(np.asarray(out.points), pts[want])
+    assert np.array_equal(np.asarray(out.colors), np.asarray(pcd.colors)[want])
+    assert subsample_point_cloud(pcd, 6000, path) is pcd
