@@ -74,7 +74,8 @@ __device__ inline int wave_max_i32(int v) {
 // hold the pair requested last (the request for the next pair goes out as soon as this one is consumed).
 // Written as one block because the compiler's version of the same loop spends a third of its instructions
 // on exec-mask bookkeeping.  Waits that gfx950 wants between dependent instructions are met by the order:
-// a packed-fp32 result is read two instructions later at the earliest, a compare's mask three later.
+// a packed-fp32 result is read two instructions later at the earliest (an LDS read or an independent add sits
+// in between), a compare's mask three later.
 __device__ inline void scan_pairs(uint32_t &j0, const uint32_t end, uint32_t &pa, uint32_t &wp, f32x2 &nx, f32x2 &ny,
                                   f32x2 &nz, const f32x2 qx, const f32x2 qy, const f32x2 qz, const uint32_t thr,
                                   const uint32_t wp_full) {
@@ -94,15 +95,12 @@ __device__ inline void scan_pairs(uint32_t &j0, const uint32_t end, uint32_t &pa
         "v_pk_mul_f32 v[120:121], v[120:121], v[120:121]\n\t"
         "ds_read2_b32 %[nx], %[pa] offset1:3\n\t"
         "ds_read2_b32 %[ny], %[pa] offset0:1 offset1:4\n\t"
-        "ds_read2_b32 %[nz], %[pa] offset0:2 offset1:5\n\t"
-        "s_nop 0\n\t"
         "v_pk_fma_f32 v[120:121], v[122:123], v[122:123], v[120:121]\n\t"
-        "s_nop 0\n\t"
+        "ds_read2_b32 %[nz], %[pa] offset0:2 offset1:5\n\t"
         "v_pk_fma_f32 v[120:121], v[124:125], v[124:125], v[120:121]\n\t"
-        "s_nop 0\n\t"
+        "v_add_u32 v127, 1, %[j0]\n\t"
         "v_and_or_b32 v126, v120, %[keep], %[j0]\n\t"
-        "v_and_or_b32 v127, v121, %[keep], %[j0]\n\t"
-        "v_add_u32 v127, 1, v127\n\t"
+        "v_and_or_b32 v127, v121, %[keep], v127\n\t"
         "v_cmp_lt_u32 %[m0], v126, %[thr]\n\t"
         "ds_write_b32 %[wp], v126 offset:256\n\t"
         "v_cmp_lt_u32 vcc, v127, %[thr]\n\t"
@@ -561,6 +559,24 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
 #ifdef ABL_NOSCAN
         if (seg_pack[0] != 0xdeadbeefu && L[3] != 7u) continue;
 #endif
+        // The wave leaves a segment when its longest lane is through: within the four face rows, and within the
+        // four diagonal rows, every lane walks its segments longest first (the length is the high half of the
+        // packed word), so that long meets long (steps per 64 queries 115 -> 108 in the model of the 10 M cloud).
+        if (!UNEVEN) {
+            auto ce = [](uint32_t &a, uint32_t &b) {
+                const uint32_t hi = max(a, b), lo = min(a, b);
+                a = hi;
+                b = lo;
+            };
+#pragma unroll
+            for (int g = 1; g < 9; g += 4) {
+                ce(seg_pack[g], seg_pack[g + 1]);
+                ce(seg_pack[g + 2], seg_pack[g + 3]);
+                ce(seg_pack[g], seg_pack[g + 2]);
+                ce(seg_pack[g + 1], seg_pack[g + 3]);
+                ce(seg_pack[g + 1], seg_pack[g + 2]);
+            }
+        }
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         const uint32_t cand_a = (uint32_t)(uintptr_t)(const lds_f32 *)cxyz;  // LDS byte address
         const uint32_t wp_full = col_a + 4u * (SEL_SLOTS - 2) * PC_WAVE;  // (wp names the last written slot)

@@ -107,6 +107,9 @@ def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0, s
                 if max(len(p) for p in park) >= slots - 1:
                     if policy == "full":
                         drain()
+                    elif policy == "quantile":
+                        hs = sorted(len(p) for p in park)
+                        drain(max(2, hs[int(len(hs) * partial / 100.0)]))
                     else:
                         drain(partial)
             if seg_drain and seg < 8:
@@ -120,8 +123,8 @@ def run(policy, slots=16, partial=8, nwaves=150, seg_drain=False, sort_segs=0, s
 
 
 if __name__ == "__main__":
-    for args in [dict(policy="partial", partial=8), dict(policy="partial", partial=8, seed_reach=1.0),
-                 dict(policy="partial", partial=8, seed_reach=1.0, sort_segs=2), dict(policy="partial", partial=6, seed_reach=1.0),
-                 dict(policy="partial", partial=8, seed_reach=1.0, slots=12)]:
+    for args in [dict(policy="partial", partial=8, seed_reach=1.0, sort_segs=2), dict(policy="quantile", partial=50, seed_reach=1.0, sort_segs=2),
+                 dict(policy="quantile", partial=75, seed_reach=1.0, sort_segs=2), dict(policy="quantile", partial=30, seed_reach=1.0, sort_segs=2),
+                 dict(policy="partial", partial=5, seed_reach=1.0, sort_segs=2), dict(policy="partial", partial=4, seed_reach=1.0, sort_segs=2)]:
         rng = np.random.default_rng(1)
         print(args, run(**args))
