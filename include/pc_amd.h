@@ -152,8 +152,11 @@ int64_t pc_sor_chunks(int64_t n);
 int pc_sor_chunk_sums(pc_ctx *ctx, const pc_grid *grid, const double *avg_dev, int compact, int64_t s_begin, int64_t s_end,
                       int what, double mean, double *partials_dev, void *stream);
 int pc_sor_chunk_finish(pc_ctx *ctx, const double *partials_dev, int64_t nchunks, double out[2], void *stream);
-/* mask[owned[i]] = avg[i] > 0 && avg[i] < threshold for the m compact rows of a rank (mask: n bytes, zeroed by the
- * caller, added elementwise over the ranks); pc_mask_select: ascending indices of the non-zero bytes. */
+/* The kept mask of the statistical filter as a bit mask over original indices (bit i of the mask = point i is kept;
+ * pc_mask_bytes(n) bytes, a multiple of 4, 4-byte aligned, zeroed by the caller): pc_sor_mask_scatter sets the bits of
+ * the m compact rows of a rank (avg[i] > 0 && avg[i] < threshold -> bit owned[i]); the ranks' masks are added
+ * elementwise (their bits are disjoint: the sum is the union); pc_mask_select: ascending indices of the set bits. */
+int64_t pc_mask_bytes(int64_t n);
 int pc_sor_mask_scatter(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, double threshold,
                         uint8_t *mask_dev, void *stream);
 int pc_mask_select(pc_ctx *ctx, const uint8_t *mask_dev, int64_t n, int32_t *out_kept_dev, int64_t *n_kept, void *stream);

@@ -144,8 +144,8 @@ class OracleEngine:
         mask[owned] = (avg > 0) & (avg < thr)
         return mask
 
-    def mask_select(self, mask):
-        return np.nonzero(mask)[0]
+    def mask_select(self, mask, n):
+        return np.nonzero(mask[:n])[0]
 
     def no_indices(self):
         return np.zeros(0, dtype=np.int64)

@@ -45,6 +45,7 @@ SYMBOLS = [
     ("pc_sor_chunks", _i64, [_i64]),
     ("pc_sor_chunk_sums", _i32, [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _dbl, _vp, _vp]),
     ("pc_sor_chunk_finish", _i32, [_vp, _vp, _i64, _pd, _vp]),
+    ("pc_mask_bytes", _i64, [_i64]),
     ("pc_sor_mask_scatter", _i32, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp]),
     ("pc_mask_select", _i32, [_vp, _vp, _i64, _vp, _pi64, _vp]),
     ("pc_sor_sum", _i32, [_vp, _vp, _i64, _pd, _pi64, _vp]),

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_scan(ScanArgs A) {
             int32_t id;
             const int64_t s = A.qlist ? (int64_t)A.qlist[qi] : A.s_begin + qi;
             RecTraits<REC>::load((A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec) + s, qx, qy, qz, id);
-            out_row = id;
+            out_row = out_row_of(A, id, s);
         } else {
             const TQ *q = reinterpret_cast<const TQ *>(A.queries) + 3 * (A.s_begin + qi);
             qx = (double)q[0];
@@ -195,6 +195,7 @@ int launch_scan(pc_ctx *ctx, const pc_grid *g, int qdtype, const ScanArgs &A0, h
 
 ScanArgs base_args(const pc_grid *g) {
     ScanArgs A{};
+    A.compact_base = -1;
     A.gp = g->gp;
     A.rec = g->rec;
     A.ci = g->index();
@@ -315,13 +316,23 @@ __global__ __launch_bounds__(256) void k_fill_slots(const int32_t *__restrict__ 
     if (s < s_end) slot[perm[s]] = (int32_t)(s - s_begin);
 }
 
+// kept bit of original index owned[i], set with an atomic OR: the whole bit mask (n / 8 bytes) stays in L2, where
+// n scattered byte stores would each rewrite a sector in HBM
 __global__ __launch_bounds__(256) void k_mask_scatter(const double *__restrict__ avg, const int32_t *__restrict__ owned,
-                                                       int64_t m, double thr, uint8_t *__restrict__ mask) {
+                                                       int64_t m, double thr, uint32_t *__restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < m) {
         const double v = avg[i];
-        mask[owned[i]] = (v > 0 && v < thr) ? 1 : 0;
+        if (v > 0 && v < thr) {
+            const uint32_t o = (uint32_t)owned[i];
+            atomicOr(&mask[o >> 5], 1u << (o & 31u));
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void k_bits_to_flags(const uint32_t *__restrict__ mask, int64_t n, uint8_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = (mask[i >> 5] >> (i & 31)) & 1u;
 }
 
 int sor_reduce(pc_ctx *ctx, int what, const double *avg, int64_t n, double mean, double out[2], hipStream_t st) {
@@ -483,11 +494,15 @@ int pc_knn_fused_compact(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int6
     hipStream_t st = (hipStream_t)stream;
     const int64_t m = s_end - s_begin;
     if (m == 0) return PC_OK;
-    // original index -> output row, for the queries of the range (other entries are never read)
-    Scratch slot(ctx, sizeof(int32_t) * (size_t)grid->n);
+    // Output row of a query: its sorted position minus s_begin.  The kernels of a single-level index know that
+    // position; the coarser levels of a multi-level index (uneven clouds) sort the points differently and look the row
+    // up by original index (map filled for the queries of the range; other entries are never read).
+    const bool by_position = grid->coarse == nullptr && !grid->uneven;
+    Scratch slot(ctx, by_position ? 0 : sizeof(int32_t) * (size_t)grid->n);
     if (!slot.ok()) return pc_fail(ctx, PC_NOMEM, "output rows");
-    hipLaunchKernelGGL(k_fill_slots, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, grid->perm, s_begin, s_end,
-                       slot.as<int32_t>());
+    if (!by_position)
+        hipLaunchKernelGGL(k_fill_slots, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, grid->perm, s_begin, s_end,
+                           slot.as<int32_t>());
     if (out_owned_dev)
         PC_HIP(hipMemcpyAsync(out_owned_dev, grid->perm + s_begin, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToDevice, st));
     ScanArgs A = base_args(grid);
@@ -501,7 +516,8 @@ int pc_knn_fused_compact(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int6
     A.out_cnt = out_cnt_dev;
     A.out_f64 = out_avg_dev;
     A.out_nrm = out_normals_dev;
-    A.out_slot = slot.as<int32_t>();
+    A.out_slot = by_position ? nullptr : slot.as<int32_t>();
+    A.compact_base = by_position ? s_begin : -1;
     if (!out_avg_dev && !out_normals_dev) return launch_scan<M_KNN>(ctx, grid, grid->dtype, A, st);  // rows only
     return launch_scan<M_ALL>(ctx, grid, grid->dtype, A, st);
 }
@@ -548,25 +564,33 @@ int pc_sor_chunk_finish(pc_ctx *ctx, const double *partials_dev, int64_t nchunks
     return PC_OK;
 }
 
+int64_t pc_mask_bytes(int64_t n) { return n > 0 ? ((n + 31) / 32) * 4 : 0; }
+
 int pc_sor_mask_scatter(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, double threshold,
                         uint8_t *mask_dev, void *stream) {
     PcLock lock(ctx, stream);
-    if (!ctx || m < 0 || (m > 0 && (!avg_dev || !owned_dev || !mask_dev))) return pc_fail(ctx, PC_BAD_ARG, "pc_sor_mask_scatter");
+    if (!ctx || m < 0 || (m > 0 && (!avg_dev || !owned_dev || !mask_dev)) || ((uintptr_t)mask_dev & 3u))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_sor_mask_scatter");
     PC_HIP(hipSetDevice(ctx->device));
     if (m == 0) return PC_OK;
     hipLaunchKernelGGL(k_mask_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, avg_dev,
-                       owned_dev, m, threshold, mask_dev);
+                       owned_dev, m, threshold, reinterpret_cast<uint32_t *>(mask_dev));
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
 
 int pc_mask_select(pc_ctx *ctx, const uint8_t *mask_dev, int64_t n, int32_t *out_kept_dev, int64_t *n_kept, void *stream) {
     PcLock lock(ctx, stream);
-    if (!ctx || n < 0 || (n > 0 && !mask_dev) || !n_kept) return pc_fail(ctx, PC_BAD_ARG, "pc_mask_select");
+    if (!ctx || n < 0 || (n > 0 && !mask_dev) || !n_kept || ((uintptr_t)mask_dev & 3u)) return pc_fail(ctx, PC_BAD_ARG, "pc_mask_select");
     PC_HIP(hipSetDevice(ctx->device));
     *n_kept = 0;
     if (n == 0) return PC_OK;
-    return pc_compact_flags(ctx, mask_dev, n, out_kept_dev, n_kept, (hipStream_t)stream);
+    Scratch flags(ctx, (size_t)n);
+    if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "mask scratch");
+    hipLaunchKernelGGL(k_bits_to_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t *>(mask_dev), n, flags.as<uint8_t>());
+    PC_HIP(hipGetLastError());
+    return pc_compact_flags(ctx, flags.as<uint8_t>(), n, out_kept_dev, n_kept, (hipStream_t)stream);
 }
 
 int pc_count_select(pc_ctx *ctx, const int32_t *cnt_dev, int64_t n, int32_t nb_points, uint8_t *out_mask_dev,

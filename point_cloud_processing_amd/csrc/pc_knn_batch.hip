@@ -277,7 +277,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     }
     A.qflag_out[qid] = 0;
     cnt = min(cnt, k);
-    emit_result<MODE>(A, (int64_t)qid, cnt, [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
+    emit_result<MODE>(A, A.out_slot ? (int64_t)A.out_slot[qid] : (int64_t)qid, cnt, [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
         d = bd[s * PC_WAVE + lane];
         RecTraits<REC>::load(rec + bp[s * PC_WAVE + lane], x, y, z, id);
     });

@@ -59,6 +59,9 @@ struct ScanArgs {
     // compact outputs (query shards): row of the outputs that original index i is written to, or NULL: row i.
     // (prior normals are not supported together with it: they are indexed by the original index.)
     const int32_t *out_slot;
+    // ... or, where the kernel knows the query's sorted position at level 0 (single-level indexes): row =
+    // position - compact_base; < 0: off
+    int64_t compact_base;
     // optional explicit list of sorted positions to answer (the exact re-run of queries that
     // the tile kernel could not certify); *qcount entries of qlist
     const int32_t *qlist;
@@ -324,13 +327,18 @@ __device__ inline void emit_normal(const ScanArgs &A, int64_t out_row, int cnt, 
 }
 
 
+// Row of the outputs for the query with original index (or query row) `id` at sorted position `spos`.
+__device__ inline int64_t out_row_of(const ScanArgs &A, int64_t id, int64_t spos) {
+    if (A.out_slot) return A.out_slot[id];
+    return A.compact_base >= 0 ? spos - A.compact_base : id;
+}
+
 // ---- per-query consumers -------------------------------------------------------------------------
 // NB(s, d2, x, y, z, idx) yields the s-th nearest neighbour (ascending (d2, idx)) of this query.
 // ONLY_NORMALS: the caller has written the rows / mean distance itself.
 template <int MODE, bool ONLY_NORMALS = false, typename NB>
 __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, NB nb) {
     const int k = A.k;
-    if (A.out_slot) out_row = A.out_slot[out_row];
     if (!ONLY_NORMALS && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
         for (int s = 0; s < k; s++) {
             int32_t id = -1;

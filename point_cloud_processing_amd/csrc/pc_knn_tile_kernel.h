@@ -748,7 +748,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         // Rows and mean distance straight from the sorted registers (no second look at the candidates);
         // the long lists of k > 20 keep fewer registers alive by going through the generic consumer.
         constexpr bool DIRECT = KS <= 22;
-        const int64_t orow = A.out_slot ? (int64_t)A.out_slot[qid] : (int64_t)qid;  // row of the outputs
+        const int64_t orow = out_row_of(A, qid, spos);  // row of the outputs
         if (DIRECT && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
             const int64_t row = orow * k;
             if ((k & 3) == 0) {  // (uniform) rows of 16-byte groups: vector stores
@@ -832,7 +832,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
 #pragma unroll
         for (int s = 0; s < KS; s++)
             if (s < k) ordbuf[s * PC_WAVE + lane] = (uint16_t)od[s];
-        emit_result<MODE, DIRECT>(A, (int64_t)qid, cnt,
+        emit_result<MODE, DIRECT>(A, orow, cnt,
                           [&](int s, double &d, double &x, double &y, double &z, int32_t &nid) {
                               const uint32_t o = ordbuf[s * PC_WAVE + lane];
                               TileRec<REC>::exact(rec, make_float4(cxyz[3 * o], cxyz[3 * o + 1], cxyz[3 * o + 2], cws[o]), x, y, z, nid);

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 if (certified) {
                     // results refer to this level's records
                     if (lane == 0) {
-                        emit_result<MODE>(A, (int64_t)qid, cnt,
+                        emit_result<MODE>(A, out_row_of(A, qid, spos), cnt,
                                           [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
                                               d = res_d[s];
                                               RecTraits<REC>::load(rec + res_pos[s], x, y, z, id);

@@ -10,7 +10,7 @@ deviation: every rank fills the per-chunk partial sums of its own slice into a z
 arrays are added elementwise (RCCL all-reduce over xGMI when the backend is "nccl"; adding the
 other ranks' zeros is exact) and every rank finishes the same array with the same fixed tree, so
 the statistics carry the same bits for 1, 2, 4 or 8 ranks.  The kept mask is exchanged the same
-way (n bytes).  Nothing else crosses GPUs, and nothing visits the host but a few scalars.
+way (one bit per point: the ranks' bits are disjoint, so the sum is the union).  Nothing else crosses GPUs, and nothing visits the host but a few scalars.
 
 Each algorithm is written once, as a generator that yields the arrays it wants summed over the
 ranks: ``run`` drives it with ``dist.all_reduce``; ``run_emulated`` drives the generators of all
@@ -105,7 +105,7 @@ def _filter_core(engine, pts, cache: dict, k: int, std_ratio: float, sh: dict, b
         std = float(np.sqrt(np.float64(sq) / np.float64(valid - 1)))
     thr = mean + std_ratio * std
     mask = yield engine.mask_scatter(sh["avg"], sh["owned"], thr, n)
-    return engine.mask_select(mask), (mean, std, thr, valid)
+    return engine.mask_select(mask, n), (mean, std, thr, valid)
 
 
 def sor_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int):

@@ -411,15 +411,14 @@ class HipEngine:
         return float(out[0]), float(out[1])
 
     def mask_scatter(self, avg, owned, thr, n) -> torch.Tensor:
-        mask = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        mask = torch.zeros((int(self.lib.pc_mask_bytes(n)),), dtype=torch.uint8, device=self.device)  # one bit per point
         self._check(self.lib.pc_sor_mask_scatter(self.ctx, _ptr(avg), _ptr(owned), avg.numel(), float(thr), _ptr(mask),
                                                  self.stream()), "pc_sor_mask_scatter")
         return mask
 
-    def mask_select(self, mask: torch.Tensor):
+    def mask_select(self, mask: torch.Tensor, n: int):
         from .geometry import LazyIndices
 
-        n = mask.numel()
         kept = self.empty((max(n, 1),), torch.int32)
         nk = C.c_int64(0)
         self._check(self.lib.pc_mask_select(self.ctx, _ptr(mask), n, _ptr(kept), C.byref(nk), self.stream()),
