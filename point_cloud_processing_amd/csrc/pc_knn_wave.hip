@@ -1,16 +1,23 @@
-// One wave per query: the exact fp64 re-run of the few queries the tile kernel could not
-// certify.  The 64 lanes stride over the candidates of the ring block around the query's cell,
-// keep those not farther than a known upper bound of the k-th distance, compact them into LDS
-// with ballot prefix sums, rank them by (d2, original index) and certify the result against
-// the block faces; an uncertified query grows its ring.  Queries whose survivor set does not
-// fit LDS go to a second list that the one-query-per-lane scan answers.
+// One wave per query: the exact fp64 re-run of the queries the tile kernels could not certify.
+// The wave looks at a block of cells around the query -- a ring of R cells at one level of the index --
+// cuts away the rows (and row ends) that lie farther than a known upper bound of the k-th distance,
+// strides its 64 lanes over the candidates that are left, keeps those within the bound, compacts them
+// into LDS with ballot prefix sums, ranks them by (d2, original index) and certifies the result against
+// the block faces.  As soon as a bound is known the next block is the smallest one, on the finest level,
+// that certainly holds everything within the bound: that block certifies.  Until then the blocks grow
+// level by level.  Queries whose survivor set does not fit LDS go to a second list that the
+// one-query-per-lane scan answers.
 #include "pc_knn_dev.h"
 
 namespace {
 
 constexpr int SCAP = 512;  // survivors one query may hold in LDS
 
-constexpr int ROW_CACHE = 256;
+constexpr int ROW_CACHE = 256;  // rows of a block kept in LDS (begin and running count): rings up to 7 cells
+
+constexpr int JUMP_RING = 4;  // a known bound picks the finest level on which a ring of at most this many cells reaches it
+
+constexpr int AHEAD = 4;  // candidate records in flight per lane
 
 template <typename REC, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
@@ -19,7 +26,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
     __shared__ int32_t sv_id[SCAP];
     __shared__ double res_d[PC_MAX_K];
     __shared__ uint32_t res_pos[PC_MAX_K];
-    __shared__ uint32_t row_b[ROW_CACHE], row_e[ROW_CACHE];  // record range of each block row
+    __shared__ uint32_t row_b[ROW_CACHE], row_off[ROW_CACHE + 1];  // first record of each block row, candidates before it
     const int lane = threadIdx.x;
     const REC *rec0 = reinterpret_cast<const REC *>(A.rec);
     const int k = A.k;
@@ -34,8 +41,28 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         RecTraits<REC>::load((A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec0) + spos, qx, qy, qz, qid);
         const double qv[3] = {qx, qy, qz};
         int cnt = 0, lvl = 0, R = 1;
-        bool spilled = false;
+        bool spilled = false, jumped = false;
+        // The finest level and ring whose block holds everything within sqrt(bound2) of the query: the ring
+        // reaches R cells beyond the query's own cell on every side, i.e. at least R * cell.
+        auto jump = [&](double bound2) -> bool {
+            const double need = sqrt(bound2) * (1.0 + 1e-6);
+            for (int l = 0; l < A.nlv; l++) {
+                const double r = ceil(need / A.lv[l].gp.cell);
+                if (r <= (double)JUMP_RING) {
+                    lvl = l;
+                    R = max(1, (int)r);
+                    return true;
+                }
+            }
+            return false;
+        };
+        {
+            const double pb0 = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;
+            if (pb0 < INFINITY) jumped = jump(pb0);
+        }
         for (;;) {
+            lvl = __builtin_amdgcn_readfirstlane(lvl);
+            R = __builtin_amdgcn_readfirstlane(R);
             // ---- the block: ring R around the query's cell at level lvl -----------------------------
             const GridParams gp = A.lv[lvl].gp;
             const REC *rec = reinterpret_cast<const REC *>(A.lv[lvl].rec);
@@ -68,21 +95,62 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             }
             const bool can_end_short = whole || (r2lim >= 0.0 && b2 >= r2lim);
             const int nry = hi[1] - lo[1] + 1, nrows = nry * (hi[2] - lo[2] + 1);
-            // population of the block: lanes over rows
-            uint32_t total = 0;
-            for (int r = lane; r < nrows; r += PC_WAVE) {
-                const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
-                const uint32_t b = cell_begin(ci, row + lo[0]), e = cell_begin(ci, row + hi[0] + 1);
-                total += e - b;
-                if (r < ROW_CACHE) {  // kept for the scan below: the searches of all rows overlap here
-                    row_b[r] = b;
-                    row_e[r] = e;
-                }
-            }
-            __syncthreads();
+            const bool flat = nrows <= ROW_CACHE;
+            const int rc = (cc[1] - lo[1]) + nry * (cc[2] - lo[2]);  // the query's own row goes first: its points bound the rest
+            const double pb = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;   // nothing farther than this (squared) is ever kept
+            const double slack = 1e-6 * gp.cell;
+            // A row of the block in scan order: its first record and its length, after cutting away what the
+            // bound excludes -- the whole row when its (y, z) slab is farther than the bound, else the cells
+            // on either end that are.
+            auto row_range = [&](int ri, uint32_t &b, uint32_t &len) {
+                const int r = ri + rc < nrows ? ri + rc : ri + rc - nrows;
+                const int ry = lo[1] + r % nry, rz = lo[2] + r / nry;
+                int x0 = lo[0], x1 = hi[0];
+                b = 0;
+                len = 0;
+                if (pb < INFINITY) {
+                    double rem = pb;
+                    const int rcell[3] = {0, ry, rz};
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+                    for (int a = 1; a < 3; a++) {
+                        const double q = qv[a] - gp.o[a];
+                        const int c = rcell[a];
+                        const double g = c > cc[a] ? (double)c * gp.cell - q : (c < cc[a] ? q - (double)(c + 1) * gp.cell : 0.0);
+                        const double gs = fmax(g - slack, 0.0);
+                        rem -= gs * gs;
+                    }
+                    if (rem < 0.0) return;
+                    const double xr = sqrt(rem) + slack, q = qv[0] - gp.o[0];
+                    const double f0 = floor((q - xr) * gp.s), f1 = floor((q + xr) * gp.s);
+                    if (f0 > (double)x1 || f1 < (double)x0) return;
+                    if (f0 > (double)x0) x0 = (int)f0;
+                    if (f1 < (double)x1) x1 = (int)f1;
+                }
+                const int64_t row = ((int64_t)rz * gp.dim[1] + ry) * gp.dim[0];
+                b = cell_begin(ci, row + x0);
+                len = cell_begin(ci, row + x1 + 1) - b;
+            };
+            // population of the block: lanes over rows (the index searches of all rows overlap here)
+            uint32_t total = 0;
+            for (int base = 0; base < nrows; base += PC_WAVE) {
+                const int ri = base + lane;
+                uint32_t b = 0, len = 0;
+                if (ri < nrows) row_range(ri, b, len);
+                uint32_t inc = len;
+#pragma unroll
+                for (int o = 1; o < PC_WAVE; o <<= 1) {
+                    const uint32_t t = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t;
+                }
+                if (flat && ri < nrows) {
+                    row_b[ri] = b;
+                    row_off[ri] = total + inc - len;
+                }
+                total += __shfl(inc, PC_WAVE - 1, 64);
+            }
             total = __builtin_amdgcn_readfirstlane(total);
+            if (flat && lane == 0) row_off[nrows] = total;
+            __syncthreads();
 
             bool certified = false;
             if (total >= (uint32_t)k || can_end_short) {
@@ -121,7 +189,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                             kept += __popcll(bal);
                         }
                         __syncthreads();
-                        ub = fmin(ub, cut);  // a bound of the true k-th distance, for later rings too
+                        ub = fmin(ub, cut);  // a bound of the true k-th distance, for later blocks too
                         if (kept == mm) break;  // ties only: nothing left to remove
                         mm = kept;
                     }
@@ -129,52 +197,71 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 };
                 uint32_t m = 0;
                 bool overflow = false;  // more equal-distance survivors than LDS holds
-                // the query's own row first: its nearest points give a tight bound at the first thinning
-                const int rc = (cc[1] - lo[1]) + nry * (cc[2] - lo[2]);
-                for (int ri = 0; ri < nrows && !overflow; ri++) {
-                    const int r = ri + rc < nrows ? ri + rc : ri + rc - nrows;
-                    const int64_t row = ((int64_t)(lo[2] + r / nry) * gp.dim[1] + (lo[1] + r % nry)) * gp.dim[0];
-                    uint32_t jb, je;
-                    if (r < ROW_CACHE) {
-                        jb = row_b[r];
-                        je = row_e[r];
-                    } else {
-                        // sparse index: lanes 0 and 1 search, the wave shares the two results
-                        uint32_t jv = 0;
-                        if (lane < 2) jv = cell_begin(ci, lane == 0 ? row + lo[0] : row + hi[0] + 1);
-                        jb = __builtin_amdgcn_readfirstlane(__shfl(jv, 0, 64));
-                        je = __builtin_amdgcn_readfirstlane(__shfl(jv, 1, 64));
+                // one batch of up to 64 loaded candidates: test against the bound, append the survivors
+                auto take = [&](bool have, uint32_t j, double px, double py, double pz, int32_t pid) {
+                    if (m > SCAP - PC_WAVE) {  // wave-uniform: make room before the next 64 candidates
+                        __syncthreads();
+                        m = thin(m);
+                        if (m > SCAP - PC_WAVE) {
+                            overflow = true;
+                            return;
+                        }
                     }
-                    for (uint32_t j0 = jb; j0 < je; j0 += PC_WAVE) {
-                        if (m > SCAP - PC_WAVE) {  // wave-uniform: make room before the next 64 candidates
-                            __syncthreads();
-                            m = thin(m);
-                            if (m > SCAP - PC_WAVE) {
-                                overflow = true;
-                                break;
+                    const double dx = qx - px, dy = qy - py, dz = qz - pz;
+                    double d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    const bool keep = have && d <= ub && !(r2lim >= 0.0 && !(d < r2lim));
+                    const unsigned long long bal = __ballot(keep);
+                    const uint32_t at = m + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (keep) {
+                        sv_d[at] = d;
+                        sv_pos[at] = j;
+                        sv_id[at] = pid;
+                    }
+                    m += __popcll(bal);
+                };
+                if (flat) {
+                    // all rows as one run of `total` candidates: every lane finds the row of its candidate by
+                    // the running counts, AHEAD records are in flight per lane
+                    for (uint32_t t0 = 0; t0 < total && !overflow; t0 += AHEAD * PC_WAVE) {
+                        uint32_t jj[AHEAD];
+                        double px[AHEAD], py[AHEAD], pz[AHEAD];
+                        int32_t pid[AHEAD];
+#pragma unroll
+                        for (int u = 0; u < AHEAD; u++) {
+                            const uint32_t t = t0 + u * PC_WAVE + lane;
+                            jj[u] = 0;
+                            px[u] = py[u] = pz[u] = 0.0;
+                            pid[u] = 0;
+                            if (t < total) {
+                                int at = 0;  // the last row that starts at or before candidate t (rows of no length start where the next does)
+#pragma unroll
+                                for (int step = ROW_CACHE / 2; step > 0; step >>= 1)
+                                    if (at + step < nrows && row_off[at + step] <= t) at += step;
+                                jj[u] = row_b[at] + (t - row_off[at]);
+                                RecTraits<REC>::load(rec + jj[u], px[u], py[u], pz[u], pid[u]);
                             }
                         }
-                        const uint32_t j = j0 + lane;
-                        bool keep = false;
-                        double d = 0.0;
-                        int32_t pid = 0;
-                        if (j < je) {
-                            double px, py, pz;
-                            RecTraits<REC>::load(rec + j, px, py, pz, pid);
-                            const double dx = qx - px, dy = qy - py, dz = qz - pz;
-                            d = dx * dx;
-                            d += dy * dy;
-                            d += dz * dz;
-                            keep = d <= ub && !(r2lim >= 0.0 && !(d < r2lim));
+#pragma unroll
+                        for (int u = 0; u < AHEAD; u++) {
+                            if (t0 + u * PC_WAVE >= total || overflow) break;
+                            take(t0 + u * PC_WAVE + lane < total, jj[u], px[u], py[u], pz[u], pid[u]);
                         }
-                        const unsigned long long bal = __ballot(keep);
-                        const uint32_t at = m + __popcll(bal & ((1ull << lane) - 1ull));
-                        if (keep) {
-                            sv_d[at] = d;
-                            sv_pos[at] = j;
-                            sv_id[at] = pid;
+                    }
+                } else {
+                    // more rows than LDS keeps (a large ring on the coarsest level): row by row
+                    for (int ri = 0; ri < nrows && !overflow; ri++) {
+                        uint32_t jv = 0, lv = 0;
+                        if (lane == 0) row_range(ri, jv, lv);
+                        const uint32_t jb = __builtin_amdgcn_readfirstlane(jv), je = jb + __builtin_amdgcn_readfirstlane(lv);
+                        for (uint32_t j0 = jb; j0 < je && !overflow; j0 += PC_WAVE) {
+                            const uint32_t j = j0 + lane;
+                            double px = 0.0, py = 0.0, pz = 0.0;
+                            int32_t pid = 0;
+                            if (j < je) RecTraits<REC>::load(rec + j, px, py, pz, pid);
+                            take(j < je, j, px, py, pz, pid);
                         }
-                        m += __popcll(bal);
                     }
                 }
                 __syncthreads();
@@ -218,9 +305,16 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 }
                 if (cnt == k) ub = fmin(ub, kth);
             }
-            // widen: ring 1 at each level in turn (block edges 3, 6, 12, ... fine cells), then ever
-            // larger rings at the coarsest level
-            if (!last_level) {
+            // The next block.  With a bound: the block that certainly holds everything within it (it certifies;
+            // should rounding at a cell face ever deny that, the ring grows from there).  Without one: ring 1
+            // at each level in turn (block edges 3, 6, 12, ... fine cells), then ever larger rings at the
+            // coarsest level.
+            const double pbn = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;
+            if (jumped) {
+                R++;
+            } else if (pbn < INFINITY && jump(pbn)) {
+                jumped = true;
+            } else if (!last_level) {
                 lvl++;
                 R = 1;
             } else {
