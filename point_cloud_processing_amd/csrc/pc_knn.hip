@@ -196,6 +196,8 @@ int launch_scan(pc_ctx *ctx, const pc_grid *g, int qdtype, const ScanArgs &A0, h
 ScanArgs base_args(const pc_grid *g) {
     ScanArgs A{};
     A.compact_base = -1;
+    A.flag_max = 255;
+    A.flag_top = 0;
     A.gp = g->gp;
     A.rec = g->rec;
     A.ci = g->index();

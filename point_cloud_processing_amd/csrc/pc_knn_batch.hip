@@ -79,6 +79,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     // A query amid more candidates than a tile pass would stage is not worth a lane here either: it
     // keeps its flag (coarser cells are fuller still, so it ends with the wave-per-query kernel).
     uint32_t total = 0;
+    uint8_t wait_flag = 1;  // the flag a query left open gets: 1 + the first level that lists it again
 #pragma unroll
     for (int seg = 0; seg < 9; seg++) total += jn[seg];
     const bool crowded = total > (uint32_t)min(A.cand_cap, (int)ORD_MASK);
@@ -97,6 +98,21 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         if (total < 2u * (uint32_t)k && !whole_grid && A.radius2 < 0.0) {
 #pragma unroll
             for (int seg = 0; seg < 9; seg++) jn[seg] = 0;
+            // The 27 cells of the next level hold about eight times as many where the cloud fills space and four
+            // times as many on a surface.  Filling space, they must hold some 4 k before k of them lie within
+            // reach (the ball is a sixth of the block, not a third as the disc on a surface): the query skips
+            // the levels where eight-fold growth stays below 4 k -- which on a surface is four-fold growth
+            // below 2 k.  (Where a denser part of the cloud comes into reach sooner, a level is missed; the
+            // passes after it, or the wave-per-query kernel, still answer exactly.)
+            if (A.flag_top > 0) {
+                uint32_t pred = max(total, 1u) * 8u;
+                int f = A.flag_max + 1;
+                while (pred < 4u * (uint32_t)k && f < A.flag_top) {
+                    pred *= 8u;
+                    f++;
+                }
+                wait_flag = (uint8_t)f;
+            }
         }
     }
     if (A.count_crowded) {  // how many queries are crowded decides whether finer grids are worth making
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     if (!ok) {
         const float ubf = nvalid >= k ? (float)(dmax * (1.0 + 1e-6)) : INFINITY;
         A.qub_arr[qid] = A.qflag_in ? fminf(A.qub_arr[qid], ubf) : ubf;
-        A.qflag_out[qid] = 1;
+        A.qflag_out[qid] = wait_flag;
         return;  // flagged for the next level
     }
     // exact order: distance (bubble passes of min/max exchanges; the list is nearly sorted), then the rare
@@ -307,36 +323,58 @@ void launch_ks(int ks, int mode, unsigned nb, hipStream_t st, const ScanArgs &A,
     }
 }
 
-// flags[s] = 1 where the record at sorted position s (of this level) belongs to an open query
+// flags[s] = 1 where the record at sorted position s (of this level) belongs to an open query that the pass
+// of flag_max answers
+// (*open_all counts every open query, also those that wait for a later pass; a thread takes OPEN_PER_THREAD
+// records a block-width apart so that the counter sees one atomic per wave and 1024 records)
+constexpr int OPEN_PER_THREAD = 16;
 template <typename REC>
 __global__ __launch_bounds__(256) void k_open_flags(const REC *__restrict__ rec, int64_t n, const uint8_t *__restrict__ qflag,
-                                                     uint8_t *__restrict__ out) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
-    double x, y, z;
-    int32_t id;
-    RecTraits<REC>::load(rec + s, x, y, z, id);
-    out[s] = qflag[id];
+                                                     int flag_max, uint8_t *__restrict__ out, uint32_t *__restrict__ open_all) {
+    const int64_t base = (int64_t)blockIdx.x * (256 * OPEN_PER_THREAD) + threadIdx.x;
+    uint32_t mine = 0;
+#pragma unroll 4
+    for (int u = 0; u < OPEN_PER_THREAD; u++) {
+        const int64_t s = base + (int64_t)u * 256;
+        if (s < n) {
+            double x, y, z;
+            int32_t id;
+            RecTraits<REC>::load(rec + s, x, y, z, id);
+            const uint8_t f = qflag[id];
+            out[s] = flag_live(f, flag_max) ? 1 : 0;
+            mine += f != 0 ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (mine && (threadIdx.x & (PC_WAVE - 1)) == 0) atomicAdd(open_all, mine);
 }
 
 }  // namespace
 
-// The open queries (qflag set) of the level whose records are `qsrc` (n of them, the level's own
-// points or external queries binned into it), as ascending sorted positions in list_out; *count on
-// the host (synchronises).
-int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, const uint8_t *qflag, int32_t *list_out,
-                       int64_t *count, hipStream_t st) {
+// The open queries (flag set and at most flag_max) of the level whose records are `qsrc` (n of them, the
+// level's own points or external queries binned into it), as ascending sorted positions in list_out;
+// *count of them and *open_all, the number of flags set at all, on the host (synchronises).  counter: one
+// device word of the caller's.
+int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, const uint8_t *qflag, int flag_max, int32_t *list_out,
+                       int64_t *count, int64_t *open_all, uint32_t *counter, hipStream_t st) {
     *count = 0;
+    *open_all = 0;
     if (n <= 0) return PC_OK;
+    PC_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
     Scratch f(ctx, (size_t)n);
     if (!f.ok()) return pc_fail(ctx, PC_NOMEM, "open-query flags");
-    const unsigned nb = (unsigned)((n + 255) / 256);
+    const unsigned nb = (unsigned)((n + 256 * OPEN_PER_THREAD - 1) / (256 * OPEN_PER_THREAD));
     if (dtype == PC_F32)
-        hipLaunchKernelGGL(k_open_flags<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)qsrc, n, qflag, f.as<uint8_t>());
+        hipLaunchKernelGGL(k_open_flags<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)qsrc, n, qflag, flag_max, f.as<uint8_t>(), counter);
     else
-        hipLaunchKernelGGL(k_open_flags<Rec64>, dim3(nb), dim3(256), 0, st, (const Rec64 *)qsrc, n, qflag, f.as<uint8_t>());
+        hipLaunchKernelGGL(k_open_flags<Rec64>, dim3(nb), dim3(256), 0, st, (const Rec64 *)qsrc, n, qflag, flag_max, f.as<uint8_t>(), counter);
     PC_HIP(hipGetLastError());
-    return pc_compact_flags(ctx, f.as<uint8_t>(), n, list_out, count, st);
+    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pinned) + 32;  // (pc_compact_flags reads its count back through the first words)
+    PC_HIP(hipMemcpyAsync(h, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    PC_TRY(pc_compact_flags(ctx, f.as<uint8_t>(), n, list_out, count, st));  // (synchronises)
+    *open_all = h[0];
+    return PC_OK;
 }
 
 // One level pass over the listed open queries (A describes the level; A.qflag_out / A.qub_arr are set).
@@ -351,3 +389,4 @@ int pc_launch_batch_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArg
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
+

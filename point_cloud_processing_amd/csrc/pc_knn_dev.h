@@ -78,6 +78,10 @@ struct ScanArgs {
     uint8_t *qflag_out;         // where uncertified queries are flagged for the next (coarser) pass;
                                 // NULL on the last pass, which appends to flag_list instead
     float *qub_arr;             // upper bound of the k-th squared distance found so far
+    // A flag is 0 (answered) or 1 + the first level that is to try the query again.  A pass answers the
+    // flagged queries whose flag is at most flag_max.
+    int flag_max;
+    int flag_top;               // the flag of the coarsest level, where passes may postpone a query by its flag; 0: they may not
     int32_t *flag_list;     // queries handed to the exact re-run (one wave per query)
     float *flag_ub;
     uint32_t *flag_count;
@@ -90,6 +94,9 @@ struct ScanArgs {
     Level lv[MAX_LEVELS];
     int nlv;
 };
+
+// an open query (flag set) that the pass of flag_max answers
+__host__ __device__ inline bool flag_live(uint8_t flag, int flag_max) { return flag != 0 && (int)flag <= flag_max; }
 
 template <typename REC>
 struct RecTraits;
@@ -401,8 +408,8 @@ void pc_tile_launch_f64(int ks, int mode, unsigned nblocks, int nw, size_t lds, 
 void pc_tile_launch_f64_split(int ks, int mode, unsigned nblocks, int nw, size_t lds, hipStream_t st, const ScanArgs &A);
 
 // pc_knn_batch.hip: a level pass over the list of still-open queries, 64 to a wave
-int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, const uint8_t *qflag, int32_t *list_out,
-                       int64_t *count, hipStream_t st);
+int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, const uint8_t *qflag, int flag_max, int32_t *list_out,
+                       int64_t *count, int64_t *open_all, uint32_t *counter, hipStream_t st);
 int pc_launch_batch_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
                          hipStream_t st);
 

@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_open_range(const REC *__restrict__ rec,
 }
 
 // chooses g->tile / g->tile_cap (once per grid)
-int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
+// listed: how many queries the level's pass is to answer, where the caller knows (coarser levels of an
+// uneven index, whose tiles are settled when the level is first searched); 0: unknown.
+int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 0) {
     if (g->tile[0] > 0) return PC_OK;
     const double occ = (double)g->n / (double)std::max<int64_t>(1, g->ncell);
     const bool dense = !g->uneven;
@@ -282,6 +284,21 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
         // grow only where the occupied cells are evenly filled (a surface of even density): the mean
         // says nothing about a cloud whose points sit mostly in a few full tiles among many empty ones
         PC_TRY(pc_grid_stats(ctx, g, st));
+        // A coarser level that is to answer millions of queries, eight or more in every occupied cell (the thin
+        // part of a big cloud: clutter between surfaces): a tile of one cell would give a wave a dozen
+        // queries, eight cells fill it; their block of 64 cells needs the larger capacity.  (66 M voxels of
+        // planes + clutter, 26 M queries answered at level 2: 116 -> 52 ms for that pass.  Small clouds and
+        // surfaces lose with the bigger tile, hence the thresholds.)
+        if (grow == 0 && g->level > 0 && g->tile[0] == 1 && listed >= (1ll << 20) && listed >= 8 * std::max<int64_t>(1, g->occupied) &&
+            !getenv("PC_AMD_UNEVEN_TILE1")) {
+            ctx->release(g->tile_list);
+            g->tile_list = nullptr;
+            g->tile_count = 0;
+            for (int a = 0; a < 3; a++) g->tile[a] = std::min(2, std::max(1, (int)g->gp.dim[a]));
+            g->tile_cap = CAND_CAP_MAX;
+            grow = 2;  // (one more turn of the loop to list the tiles, then done)
+            continue;
+        }
         const double pop = (double)g->n / (double)std::max<int64_t>(1, g->tile_count);
         const double cell_mean = (double)g->n / (double)std::max<int64_t>(1, g->occupied);
         if (pop >= 16.0 || g->occupied <= 0 || g->seen > 2.0 * (cell_mean + 1.0)) break;
@@ -343,6 +360,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     int nlv = 0;
     for (const pc_grid *l = g; l && nlv < MAX_LEVELS; l = l->coarse) lv[nlv++] = l;
     for (int i = 0; i < nlv; i++) {
+        if (i > 0 && lv[i]->uneven && lv[i]->tile[0] <= 0) continue;  // (settled when the level is first searched, below)
         PC_TRY(choose_tile(ctx, lv[i], st));
         int64_t nt = 1;
         for (int a = 0; a < 3; a++) nt *= (lv[i]->gp.dim[a] + lv[i]->tile[a] - 1) / lv[i]->tile[a];
@@ -386,6 +404,15 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     const size_t qrec_bytes = (g->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64)) * (size_t)A.nq;
     Scratch qrec_l(ctx, A.qrec && nlv > 1 ? qrec_bytes : 0), qkeys_l(ctx, A.qrec && nlv > 1 ? sizeof(uint32_t) * (size_t)A.nq : 0);
     if (!qrec_l.ok() || !qkeys_l.ok()) return pc_fail(ctx, PC_NOMEM, "query records");
+    // Postponed queries (self-queries of k-nearest searches on multi-level indexes): a list pass that finds
+    // far too few candidates around a query names, in the query's flag, the first level worth trying again,
+    // and no pass before that level lists the query.  (66 M voxels of planes + clutter: the 29 M clutter
+    // points, answered at level 2, no longer ride through a pass at level 1 that can only look up their cells.)
+    const bool hinted = qflag != nullptr && !A.qrec && A.radius2 < 0.0 && batch_passes && ks <= batch_max_ks &&
+                        !getenv("PC_AMD_NO_HINTS");
+    A.flag_top = hinted ? nlv : 0;
+    uint32_t *open_counter = A.flag_count + 28;
+    int64_t open_all = 0;
     for (int i = 0; i < nlv; i++) {
         const pc_grid *l = lv[i];
         if (A.qrec && i > 0) {
@@ -397,6 +424,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.gp = l->gp;
         A.rec = l->rec;
         A.ci = l->index();
+        if (l->tile[0] <= 0) PC_TRY(choose_tile(ctx, l, st, hinted && list_level == i ? list_count : 0));
         int64_t nt = 1;
         for (int a = 0; a < 3; a++) {
             A.tile[a] = l->tile[a];
@@ -409,9 +437,11 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         // tile; external queries on coarser levels always -- is answered from the list of open queries,
         // 64 to a wave, instead of a workgroup per tile (measured on surfaces, clusters and planes + clutter:
         // thresholds from 8 to "always" within 10 % of each other, 3 clearly slower).  Below 64 Ki queries the
-        // list would not fill the GPU's wave slots and the tile pass, one workgroup per tile, wins.
+        // list would not fill the GPU's wave slots and the tile pass, one workgroup per tile, wins -- unless the
+        // tiles outnumber the queries, most of them holding none.
+        const int64_t listed = hinted && list_level == i ? list_count : open_prev;  // queries this pass answers
         const bool batch = batch_passes && ks <= batch_max_ks && qflag != nullptr &&
-                           (i > 0 ? (A.qrec || (open_prev >= batch_min && open_prev < batch_ratio * std::max<int64_t>(nt, 1)))
+                           (i > 0 ? (A.qrec || ((listed >= batch_min || listed < nt) && listed < batch_ratio * std::max<int64_t>(nt, 1)))
                                   : (!A.qrec && l->uneven && A.nq >= batch_min && A.nq < batch_ratio * std::max<int64_t>(nt, 1)));
         if (A.qrec && l->tile_list && !batch) {
             // the grid's list names the tiles that hold POINTS; external queries need the tiles that hold
@@ -425,6 +455,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.halves = l->halves && !l->uneven && g->dtype == PC_F32 ? 1 : 0;
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
+        A.flag_max = hinted ? i + 1 : 255;
         A.count_crowded = i == 0;
         // First pass of an uneven cloud that the list kernel would take: where the cloud is dense (surfaces
         // in a sea of clutter) whole tiles are full of queries that share one candidate block, which is the
@@ -489,7 +520,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.tile_list = l->tile_list;
             A.count_crowded = 1;
             int64_t nopen = 0;
-            PC_TRY(pc_batch_open_list(ctx, g->dtype, l->rec, l->n, qflag, open_list, &nopen, st));
+            PC_TRY(pc_batch_open_list(ctx, g->dtype, l->rec, l->n, qflag, A.flag_max, open_list, &nopen, &open_all, open_counter, st));
             if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass 0: %lld open queries\n", (long long)nopen);
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
         } else if (batch) {
@@ -497,9 +528,12 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             if (i > 0 && list_level == i)
                 nopen = list_count;  // made when the previous pass was counted
             else if (i > 0)
-                PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, open_list, &nopen, st));
+                PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, A.flag_max, open_list,
+                                          &nopen, &open_all, open_counter, st));
             if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass %d: %lld open queries\n", i, (long long)nopen);
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, i > 0 ? open_list : nullptr, nopen, st));
+        } else if (hinted && i > 0 && list_level == i && list_count == 0) {
+            // (no open query starts at or before this level)
         } else {
             if (nt <= 0) continue;
             const int nw = l->uneven ? uneven_waves(nt) : std::max(1, l->tile_waves);
@@ -533,9 +567,9 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                     PC_TRY(pc_bin_queries(ctx, nl, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
                     binned_level = i + 1;
                 }
-                PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : nl->rec, qrec0 ? A.nq : nl->n, qflag, open_list, &open, st));
-                list_level = i + 1;
-                list_count = open;
+                PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : nl->rec, qrec0 ? A.nq : nl->n, qflag,
+                                          hinted ? i + 2 : 255, open_list, &list_count, &open, open_counter, st));
+                list_level = i + 1;  // (listed: the queries the next level is to try; open: those and the ones that wait for a later one)
             } else {
                 PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
             }
@@ -581,8 +615,11 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.cand_cap = uneven_cap();
             A.qflag_in = qflag;
             A.qflag_out = qflag;
+            A.flag_max = 255;
+            A.flag_top = 0;
             int64_t nopen = 0, open = 0;
-            PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : fine->rec, qrec0 ? A.nq : fine->n, qflag, open_list, &nopen, st));
+            PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : fine->rec, qrec0 ? A.nq : fine->n, qflag, 255, open_list, &nopen,
+                                      &open_all, open_counter, st));
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
             PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
             if (getenv("PC_AMD_DEBUG"))

@@ -256,6 +256,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     const bool too_many = ncand > (uint32_t)A.cand_cap;
     const bool splittable = may_split && (ext[0] > 1 || ext[1] > 1 || ext[2] > 1);
     if (A.qflag_in && too_many && !splittable) return 0;  // flagged points of an over-full block stay flagged
+    if (too_many && splittable) return 1;                 // (before looking for flagged points: a coarse tile holds millions)
     if (A.qflag_in) {
         // later passes answer only the points an earlier pass flagged: leave if the tile has none
         bool any = false;
@@ -274,12 +275,11 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 double x, y, z;
                 int32_t id;
                 RecTraits<REC>::load(qsrc + sp, x, y, z, id);
-                any = any || A.qflag_in[id] != 0;
+                any = any || flag_live(A.qflag_in[id], A.flag_max);
             }
         }
         if (!__any(any)) return 0;
     }
-    if (too_many && splittable) return 1;
 
     // over-full blocks do not fit LDS; blocks with fewer than k points cannot certify anything unless
     // they are the whole grid: both go straight to the re-run list
@@ -380,7 +380,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         bool live = active;  // a query this pass has to answer
         if (active) {
             RecTraits<REC>::load(qsrc + spos, qxd, qyd, qzd, qid);
-            if (A.qflag_in) live = A.qflag_in[qid] != 0;
+            if (A.qflag_in) live = flag_live(A.qflag_in[qid], A.flag_max);
         }
         if (!__any(live)) continue;
         if (overfull) {
