@@ -10,6 +10,7 @@
 #include "pc_amd.h"
 
 constexpr int MAX_LEVELS = 8;  // resolution levels of one spatial index (pc_grid::coarse chain)
+constexpr int MAX_FINER = 3;   // grids of half the cell edge each, made for the queries too crowded for level 0 (pc_grid::finer chain)
 
 #define PC_WAVE 64  // gfx950 wavefront width (hard-coded: not a host compile-time constant)
 

@@ -24,6 +24,42 @@ __device__ inline uint32_t cell_begin(const CellIndex &ci, int64_t key) {
     return lo;
 }
 
+// cell_begin of two cells of one (y, z) row at once (key0 <= key1; key1 may be the first cell of the next
+// row): the two searches of the sparse form run in step, their loads in flight together.
+__device__ inline void cell_range(const CellIndex &ci, int64_t key0, int64_t key1, uint32_t &b, uint32_t &e) {
+    if (ci.table) {
+        b = ci.table[key0];
+        e = ci.table[key1];
+        return;
+    }
+    uint32_t lo = 0, hi = ci.n;
+    if (ci.row_start) {
+        const uint32_t row = (uint32_t)(key0 / ci.nx);
+        lo = ci.row_start[row];
+        hi = ci.row_start[row + 1];
+    }
+    uint32_t lo0 = lo, hi0 = hi, lo1 = lo, hi1 = hi;
+    while (lo0 < hi0 || lo1 < hi1) {
+        const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+        const bool go0 = lo0 < hi0, go1 = lo1 < hi1;
+        const int64_t k0 = go0 ? (int64_t)ci.keys[m0] : 0, k1 = go1 ? (int64_t)ci.keys[m1] : 0;
+        if (go0) {
+            if (k0 < key0)
+                lo0 = m0 + 1;
+            else
+                hi0 = m0;
+        }
+        if (go1) {
+            if (k1 < key1)
+                lo1 = m1 + 1;
+            else
+                hi1 = m1;
+        }
+    }
+    b = lo0;
+    e = lo1;
+}
+
 enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4, M_ALL = 5 };
 
 // one resolution level of the spatial index
@@ -91,7 +127,7 @@ struct ScanArgs {
     int halves;             // the records of a cell are ordered low x-half first (fp32 grids of evenly filled clouds)
     int count_crowded;      // this pass counts the queries amid more candidates than a tile stages (flag_count[26])
     // wave-per-query re-run: the index levels, finest first
-    Level lv[MAX_LEVELS];
+    Level lv[MAX_LEVELS + MAX_FINER];  // (the finer grids made for crowded queries come first)
     int nlv;
 };
 

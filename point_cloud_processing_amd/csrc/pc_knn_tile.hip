@@ -504,6 +504,12 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                                       [](uint32_t a, uint64_t b) { return (uint64_t)a < b; }) - l->full_host.begin();
             }
             A.tile_list = l->full_tiles + f0;
+            // (Full tiles are where the cloud is dense.  Where they hold a hundred points and more, their blocks
+            // of 64 cells often exceed the usual capacity and the tile falls apart into its eight parts: the
+            // largest block keeps them whole -- 66 M voxels of planes + clutter, 137 points per full tile: 72 ->
+            // 60 ms for this pass.  Thinner ones only lose LDS occupancy to it: 4 M points, 79 per full tile,
+            // 16.5 -> 17.5 ms for the whole search.)
+            if (!getenv("PC_AMD_UNEVEN_CAP") && l->full_points >= 100 * l->full_count) A.cand_cap = CAND_CAP_MAX;
             const int nw = uneven_waves(f1 - f0);
             const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (3 * MAX_ROWS + 4) +
                                (A.halves ? 2 : 1) * sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
@@ -518,6 +524,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                 pc_tile_launch_f64_split(ks, mode, (unsigned)(f1 - f0), nw, lds, st, A);
             PC_HIP(hipGetLastError());
             A.tile_list = l->tile_list;
+            A.cand_cap = l->tile_cap;
             A.count_crowded = 1;
             int64_t nopen = 0;
             PC_TRY(pc_batch_open_list(ctx, g->dtype, l->rec, l->n, qflag, A.flag_max, open_list, &nopen, &open_all, open_counter, st));
@@ -599,7 +606,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     }
     if (crowded >= std::max<int64_t>(2048, A.nq / 100)) {
         const pc_grid *fine = g;
-        for (int f = 0; f < 3; f++) {
+        for (int f = 0; f < MAX_FINER; f++) {
             const pc_grid *nf = nullptr;
             PC_TRY(pc_grid_finer(ctx, fine, st, &nf));
             if (!nf) break;

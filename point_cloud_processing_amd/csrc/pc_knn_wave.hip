@@ -19,6 +19,8 @@ constexpr int JUMP_RING = 4;  // a known bound picks the finest level on which a
 
 constexpr int AHEAD = 4;  // candidate records in flight per lane
 
+constexpr uint32_t PROBE_MIN = 2048, PROBE_LEN = 512;  // blocks with more candidates are probed first, with so many
+
 template <typename REC, int MODE>
 __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
     __shared__ double sv_d[SCAP];
@@ -26,6 +28,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
     __shared__ int32_t sv_id[SCAP];
     __shared__ double res_d[PC_MAX_K];
     __shared__ uint32_t res_pos[PC_MAX_K];
+    __shared__ double res_x[PC_MAX_K], res_y[PC_MAX_K], res_z[PC_MAX_K];
+    __shared__ int32_t res_id[PC_MAX_K];
     __shared__ uint32_t row_b[ROW_CACHE], row_off[ROW_CACHE + 1];  // first record of each block row, candidates before it
     const int lane = threadIdx.x;
     const REC *rec0 = reinterpret_cast<const REC *>(A.rec);
@@ -42,6 +46,15 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         const double qv[3] = {qx, qy, qz};
         int cnt = 0, lvl = 0, R = 1;
         bool spilled = false, jumped = false;
+#ifdef PC_WAVE_DEBUG
+        const unsigned long long dbg_t0 = wall_clock64();
+        unsigned long long dbg_cand = 0;
+        int dbg_steps = 0;
+        unsigned long long dbg_sec[5] = {0, 0, 0, 0, 0}, dbg_mark = dbg_t0;
+#define DBG_LAP(i) { const unsigned long long now_ = wall_clock64(); dbg_sec[i] += now_ - dbg_mark; dbg_mark = now_; }
+#else
+#define DBG_LAP(i)
+#endif
         // The finest level and ring whose block holds everything within sqrt(bound2) of the query: the ring
         // reaches R cells beyond the query's own cell on every side, i.e. at least R * cell.
         auto jump = [&](double bound2) -> bool {
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             const int nry = hi[1] - lo[1] + 1, nrows = nry * (hi[2] - lo[2] + 1);
             const bool flat = nrows <= ROW_CACHE;
             const int rc = (cc[1] - lo[1]) + nry * (cc[2] - lo[2]);  // the query's own row goes first: its points bound the rest
-            const double pb = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;   // nothing farther than this (squared) is ever kept
+            double pb = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;   // nothing farther than this (squared) is ever kept
             const double slack = 1e-6 * gp.cell;
             // A row of the block in scan order: its first record and its length, after cutting away what the
             // bound excludes -- the whole row when its (y, z) slab is farther than the bound, else the cells
@@ -127,32 +140,44 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     if (f1 < (double)x1) x1 = (int)f1;
                 }
                 const int64_t row = ((int64_t)rz * gp.dim[1] + ry) * gp.dim[0];
-                b = cell_begin(ci, row + x0);
-                len = cell_begin(ci, row + x1 + 1) - b;
+                uint32_t e;
+                cell_range(ci, row + x0, row + x1 + 1, b, e);
+                len = e - b;
             };
-            // population of the block: lanes over rows (the index searches of all rows overlap here)
-            uint32_t total = 0;
-            for (int base = 0; base < nrows; base += PC_WAVE) {
-                const int ri = base + lane;
-                uint32_t b = 0, len = 0;
-                if (ri < nrows) row_range(ri, b, len);
-                uint32_t inc = len;
+            // population of the block under the bound pb: lanes over rows (the index searches of all rows
+            // overlap here); the rows' begins and running counts go to LDS
+            auto build_rows = [&]() -> uint32_t {
+                uint32_t total = 0;
+                for (int base = 0; base < nrows; base += PC_WAVE) {
+                    const int ri = base + lane;
+                    uint32_t b = 0, len = 0;
+                    if (ri < nrows) row_range(ri, b, len);
+                    uint32_t inc = len;
 #pragma unroll
-                for (int o = 1; o < PC_WAVE; o <<= 1) {
-                    const uint32_t t = __shfl_up(inc, o, 64);
-                    if (lane >= o) inc += t;
+                    for (int o = 1; o < PC_WAVE; o <<= 1) {
+                        const uint32_t t = __shfl_up(inc, o, 64);
+                        if (lane >= o) inc += t;
+                    }
+                    if (flat && ri < nrows) {
+                        row_b[ri] = b;
+                        row_off[ri] = total + inc - len;
+                    }
+                    total += __shfl(inc, PC_WAVE - 1, 64);
                 }
-                if (flat && ri < nrows) {
-                    row_b[ri] = b;
-                    row_off[ri] = total + inc - len;
-                }
-                total += __shfl(inc, PC_WAVE - 1, 64);
-            }
-            total = __builtin_amdgcn_readfirstlane(total);
-            if (flat && lane == 0) row_off[nrows] = total;
-            __syncthreads();
+                total = __builtin_amdgcn_readfirstlane(total);
+                if (flat && lane == 0) row_off[nrows] = total;
+                __syncthreads();
+                return total;
+            };
+            DBG_LAP(0)
+            uint32_t total = build_rows();
+            DBG_LAP(1)
 
             bool certified = false;
+#ifdef PC_WAVE_DEBUG
+            dbg_steps++;
+            if (total >= (uint32_t)k || can_end_short) dbg_cand += total;
+#endif
             if (total >= (uint32_t)k || can_end_short) {
                 // ---- survivors: candidates not farther than the bound, compacted into LDS ---------------
                 // Thinning inside LDS: the k-th smallest of ANY 64 held survivors bounds the true k-th
@@ -221,34 +246,62 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     }
                     m += __popcll(bal);
                 };
-                if (flat) {
-                    // all rows as one run of `total` candidates: every lane finds the row of its candidate by
-                    // the running counts, AHEAD records are in flight per lane
-                    for (uint32_t t0 = 0; t0 < total && !overflow; t0 += AHEAD * PC_WAVE) {
+                // all rows as one run of `total` candidates, the first `limit` of them: every lane finds the row of
+                // its candidate by the running counts (one row for the whole batch where rows are long), AHEAD
+                // records are in flight per lane
+                auto scan_flat = [&](uint32_t limit) {
+                    int cur = 0;  // the row of the batch's first candidate (uniform)
+                    for (uint32_t t0 = 0; t0 < limit && !overflow; t0 += AHEAD * PC_WAVE) {
                         uint32_t jj[AHEAD];
                         double px[AHEAD], py[AHEAD], pz[AHEAD];
                         int32_t pid[AHEAD];
 #pragma unroll
                         for (int u = 0; u < AHEAD; u++) {
-                            const uint32_t t = t0 + u * PC_WAVE + lane;
+                            const uint32_t tf = t0 + u * PC_WAVE, t = tf + lane;
                             jj[u] = 0;
                             px[u] = py[u] = pz[u] = 0.0;
                             pid[u] = 0;
-                            if (t < total) {
-                                int at = 0;  // the last row that starts at or before candidate t (rows of no length start where the next does)
+                            if (tf >= limit) continue;  // uniform
+                            while (cur + 1 < nrows && row_off[cur + 1] <= tf) cur++;
+                            const bool one_row = cur + 1 >= nrows || row_off[cur + 1] > tf + (PC_WAVE - 1);
+                            if (t < limit) {
+                                int at = cur;
+                                if (!one_row) {
+                                    at = 0;  // the last row that starts at or before candidate t (rows of no length start where the next does)
 #pragma unroll
-                                for (int step = ROW_CACHE / 2; step > 0; step >>= 1)
-                                    if (at + step < nrows && row_off[at + step] <= t) at += step;
+                                    for (int step = ROW_CACHE / 2; step > 0; step >>= 1)
+                                        if (at + step < nrows && row_off[at + step] <= t) at += step;
+                                }
                                 jj[u] = row_b[at] + (t - row_off[at]);
                                 RecTraits<REC>::load(rec + jj[u], px[u], py[u], pz[u], pid[u]);
                             }
                         }
 #pragma unroll
                         for (int u = 0; u < AHEAD; u++) {
-                            if (t0 + u * PC_WAVE >= total || overflow) break;
-                            take(t0 + u * PC_WAVE + lane < total, jj[u], px[u], py[u], pz[u], pid[u]);
+                            if (t0 + u * PC_WAVE >= limit || overflow) break;
+                            take(t0 + u * PC_WAVE + lane < limit, jj[u], px[u], py[u], pz[u], pid[u]);
                         }
                     }
+                };
+                // A big block under a loose (or no) bound: the first few hundred candidates -- the query's own
+                // row first -- give a bound, the rows are cut again under it, and so on while that still removes
+                // a quarter of the block.  (A stray point next to a cluster: 185 000 candidates in its first
+                // block with k points, 2.7 ms for one wave to look at them all.)
+                for (int probe = 0; probe < 6 && flat && total > PROBE_MIN && !can_end_short; probe++) {
+                    const double ub0 = ub;
+                    scan_flat(PROBE_LEN);
+                    __syncthreads();
+                    if (!overflow) thin(m);
+                    m = 0;
+                    overflow = false;
+                    if (!(ub < ub0)) break;  // nothing learned
+                    pb = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;
+                    const uint32_t before = total;
+                    total = build_rows();
+                    if (4ull * total > 3ull * before) break;
+                }
+                if (flat) {
+                    scan_flat(total);
                 } else {
                     // more rows than LDS keeps (a large ring on the coarsest level): row by row
                     for (int ri = 0; ri < nrows && !overflow; ri++) {
@@ -265,6 +318,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     }
                 }
                 __syncthreads();
+                DBG_LAP(2)
                 if (overflow) {
                     spilled = true;
                     break;
@@ -288,17 +342,31 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     }
                 }
                 __syncthreads();
+                DBG_LAP(3)
                 cnt = (int)min(mm, (uint32_t)k);
                 const double kth = cnt == k ? res_d[k - 1] : INFINITY;
                 __syncthreads();
                 certified = can_end_short || (cnt == k && kth <= b2);
                 if (certified) {
-                    // results refer to this level's records
+                    // results refer to this level's records: fetched by the lanes side by side, consumed by one
+                    if (lane < cnt) {
+                        double x, y, z;
+                        int32_t id;
+                        RecTraits<REC>::load(rec + res_pos[lane], x, y, z, id);
+                        res_x[lane] = x;
+                        res_y[lane] = y;
+                        res_z[lane] = z;
+                        res_id[lane] = id;
+                    }
+                    __syncthreads();
                     if (lane == 0) {
                         emit_result<MODE>(A, out_row_of(A, qid, spos), cnt,
                                           [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
                                               d = res_d[s];
-                                              RecTraits<REC>::load(rec + res_pos[s], x, y, z, id);
+                                              x = res_x[s];
+                                              y = res_y[s];
+                                              z = res_z[s];
+                                              id = res_id[s];
                                           });
                     }
                     break;
@@ -321,6 +389,20 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 R++;
             }
         }
+#ifdef PC_WAVE_DEBUG
+        if (lane == 0) {
+            const unsigned long long dt = wall_clock64() - dbg_t0;  // 100 MHz ticks
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(A.flag_count + 40);
+            atomicAdd(dbg + 0, dt);
+            atomicMax(dbg + 1, dt);
+            atomicAdd(dbg + 2, dbg_cand);
+            atomicMax(dbg + 3, dbg_cand);
+            atomicAdd(dbg + 4, (unsigned long long)dbg_steps);
+            atomicMax(dbg + 5, (unsigned long long)dbg_steps);
+            for (int i = 0; i < 5; i++) atomicAdd(dbg + 6 + i, dbg_sec[i]);
+            atomicAdd(dbg + 11, wall_clock64() - dbg_mark);
+        }
+#endif
         if (spilled && lane == 0) {
             const uint32_t p = atomicAdd(A.flag2_count, 1u);
             if (p < A.flag_cap) A.flag2_list[p] = (int32_t)spos;
@@ -347,7 +429,21 @@ void launch_wave(int mode, unsigned nb, hipStream_t st, const ScanArgs &A) {
 int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A0, hipStream_t st) {
     ScanArgs A = A0;
     A.nlv = 0;
-    for (const pc_grid *l = g; l && A.nlv < MAX_LEVELS; l = l->coarse) {
+    // the finer grids that exist already, finest first: a query in a crowded corner of the cloud finds k
+    // neighbours within a few of their cells, where level 0 would have it scan tens of thousands of points
+    {
+        const pc_grid *fine[MAX_FINER];
+        int nf = 0;
+        for (const pc_grid *f = g->finer; f && nf < MAX_FINER; f = f->finer) fine[nf++] = f;
+        while (nf > 0) {
+            const pc_grid *l = fine[--nf];
+            A.lv[A.nlv].gp = l->gp;
+            A.lv[A.nlv].rec = l->rec;
+            A.lv[A.nlv].ci = l->index();
+            A.nlv++;
+        }
+    }
+    for (const pc_grid *l = g; l && A.nlv < MAX_LEVELS + MAX_FINER; l = l->coarse) {
         A.lv[A.nlv].gp = l->gp;
         A.lv[A.nlv].rec = l->rec;
         A.lv[A.nlv].ci = l->index();
@@ -359,5 +455,17 @@ int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs
     else
         launch_wave<Rec64>(mode, nb, st, A);
     PC_HIP(hipGetLastError());
+#ifdef PC_WAVE_DEBUG
+    {
+        unsigned long long h[12];
+        hipStreamSynchronize(st);
+        hipMemcpy(h, A.flag_count + 40, sizeof(h), hipMemcpyDeviceToHost);
+        unsigned int nqh = 0;
+        hipMemcpy(&nqh, A.qcount, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[wave] queries %u: ticks sum %llu max %llu, cand sum %llu max %llu, steps sum %llu max %llu; sections setup/rows/scan/rank/-/tail", nqh, h[0], h[1], h[2], h[3], h[4], h[5]);
+        for (int i = 0; i < 6; i++) fprintf(stderr, " %llu", h[6 + i]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return PC_OK;
 }
