@@ -19,7 +19,8 @@ namespace {
 constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
 constexpr int ORD_BITS = 11;   // a lane's candidates are numbered below 2^11 (crowded queries are left out)
 constexpr uint32_t ORD_MASK = (1u << ORD_BITS) - 1;
-constexpr int PARK_SLOTS = 14; // parked keys per lane between two sorted insertions
+constexpr int PARK_SLOTS = 16; // parked keys per lane between two sorted insertions
+constexpr int AHEAD = 4;       // candidate records in flight per lane
 
 template <int KS>
 __device__ inline void key_insert(uint32_t (&L)[KS], uint32_t key) {
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         jn[seg] = 0;
         if (active && y >= 0 && y < gp.dim[1] && z >= 0 && z < gp.dim[2]) {
             const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
-            jb[seg] = cell_begin(A.ci, row + x0);
-            jn[seg] = cell_begin(A.ci, row + x1 + 1) - jb[seg];
+            uint32_t je;
+            cell_range(A.ci, row + x0, row + x1 + 1, jb[seg], je);
+            jn[seg] = je - jb[seg];
         }
     }
     // A query amid more candidates than a tile pass would stage is not worth a lane here either: it
@@ -159,19 +161,32 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
         thr = L[KS - 1];
         parked = 0;
     };
+    // AHEAD candidates per turn: their records are requested back to back, with no branch around the loads (a
+    // lane past the end of its segment re-reads the segment's last record -- record 0 if it has none -- and
+    // drops it), so that the wave waits for memory once per turn, not once per candidate
 #pragma unroll
     for (int seg = 0; seg < 9; seg++) {
+        const uint32_t n = jn[seg];
+        const uint32_t jlast = n ? jb[seg] + n - 1u : 0u;
 #pragma nounroll
-        for (int t = 0; t < tmax[seg]; t++) {
-            if ((uint32_t)t < jn[seg]) {
+        for (int t = 0; t < tmax[seg]; t += AHEAD) {
+            double d[AHEAD];
+#pragma unroll
+            for (int u = 0; u < AHEAD; u++) {
                 int32_t pid;
-                const uint32_t key = (__float_as_uint((float)dist2(jb[seg] + t, pid)) & ~ORD_MASK) | (base[seg] + t);
-                if (key < thr) {
-                    park[parked * PC_WAVE + lane] = key;
-                    parked++;
+                d[u] = dist2(n ? min(jb[seg] + (uint32_t)(t + u), jlast) : 0u, pid);
+            }
+#pragma unroll
+            for (int u = 0; u < AHEAD; u++) {
+                if ((uint32_t)(t + u) < n) {
+                    const uint32_t key = (__float_as_uint((float)d[u]) & ~ORD_MASK) | (base[seg] + (uint32_t)(t + u));
+                    if (key < thr) {
+                        park[parked * PC_WAVE + lane] = key;
+                        parked++;
+                    }
                 }
             }
-            if (__any(parked >= PARK_SLOTS)) drain();
+            if (__any(parked > PARK_SLOTS - AHEAD)) drain();
         }
     }
     drain();
@@ -212,26 +227,47 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     uint32_t jj[KS];
     int nsafe = 0, cnt = 0, nvalid = 0;
     double dmax = 0.0;
+    // (the survivors' records likewise: AHEAD loads in flight, empty slots read record 0 and drop it)
 #pragma unroll
     for (int s = 0; s < KS; s++) {
         dd[s] = INFINITY;
         jj[s] = 0;
-        if (L[s] != KEY_NONE) {
-            const uint32_t o = L[s] & ORD_MASK;
-            uint32_t j = 0;
+    }
 #pragma unroll
-            for (int seg = 0; seg < 9; seg++)
-                if (o >= base[seg]) j = jb[seg] + (o - base[seg]);
+    for (int s0 = 0; s0 < KS; s0 += AHEAD) {
+        double dv[AHEAD];
+        uint32_t jv[AHEAD];
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) {
+            jv[u] = 0;
+            if (s0 + u < KS) {
+                const uint32_t o = L[s0 + u] & ORD_MASK;
+                uint32_t j = 0;
+#pragma unroll
+                for (int seg = 0; seg < 9; seg++)
+                    if (o >= base[seg]) j = jb[seg] + (o - base[seg]);
+                jv[u] = L[s0 + u] != KEY_NONE ? j : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) {
             int32_t pid;
-            const double d = dist2(j, pid);
-            jj[s] = j;
-            nvalid++;
-            dmax = fmax(dmax, d);
-            if (d < bound) {
-                nsafe++;
-                if (!(r2lim >= 0.0 && !(d < r2lim))) {
-                    dd[s] = d;
-                    cnt++;
+            dv[u] = dist2(jv[u], pid);
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) {
+            if (s0 + u < KS && L[s0 + u] != KEY_NONE) {
+                const int s = s0 + u;
+                const double d = dv[u];
+                jj[s] = jv[u];
+                nvalid++;
+                dmax = fmax(dmax, d);
+                if (d < bound) {
+                    nsafe++;
+                    if (!(r2lim >= 0.0 && !(d < r2lim))) {
+                        dd[s] = d;
+                        cnt++;
+                    }
                 }
             }
         }

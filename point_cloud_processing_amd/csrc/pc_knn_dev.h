@@ -25,39 +25,56 @@ __device__ inline uint32_t cell_begin(const CellIndex &ci, int64_t key) {
 }
 
 // cell_begin of two cells of one (y, z) row at once (key0 <= key1; key1 may be the first cell of the next
-// row): the two searches of the sparse form run in step, their loads in flight together.
+// row).  The sparse form is searched eight ways at a time, both searches in step: a look-up is a chain of
+// dependent loads from a large array, each a likely TLB miss for a wave on its own, so the chain is kept
+// short -- seven keys per search and round trip narrow a row of 4096 records in four trips, not twelve.
 __device__ inline void cell_range(const CellIndex &ci, int64_t key0, int64_t key1, uint32_t &b, uint32_t &e) {
     if (ci.table) {
         b = ci.table[key0];
         e = ci.table[key1];
         return;
     }
-    uint32_t lo = 0, hi = ci.n;
+    uint32_t lo[2] = {0, 0}, hi[2] = {ci.n, ci.n};
     if (ci.row_start) {
         const uint32_t row = (uint32_t)(key0 / ci.nx);
-        lo = ci.row_start[row];
-        hi = ci.row_start[row + 1];
+        lo[0] = lo[1] = ci.row_start[row];
+        hi[0] = hi[1] = ci.row_start[row + 1];
     }
-    uint32_t lo0 = lo, hi0 = hi, lo1 = lo, hi1 = hi;
-    while (lo0 < hi0 || lo1 < hi1) {
-        const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-        const bool go0 = lo0 < hi0, go1 = lo1 < hi1;
-        const int64_t k0 = go0 ? (int64_t)ci.keys[m0] : 0, k1 = go1 ? (int64_t)ci.keys[m1] : 0;
-        if (go0) {
-            if (k0 < key0)
-                lo0 = m0 + 1;
-            else
-                hi0 = m0;
+    const int64_t key[2] = {key0, key1};
+    const uint32_t last = ci.n - 1u;  // (the loop runs only where ci.n > 0)
+    while (lo[0] < hi[0] || lo[1] < hi[1]) {
+        uint32_t kv[2][7], step[2];
+        // all fourteen loads first, none of them under a branch (addresses past a range are clamped and
+        // their values not used): they are in flight together and waited for once
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t len = hi[q] - lo[q];
+            // len <= 7: the entries themselves; else seven pivots an eighth of the range apart
+            step[q] = len <= 7u ? 1u : len >> 3;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const uint32_t at = lo[q] + (len <= 7u ? (uint32_t)i : (uint32_t)(i + 1) * step[q] - 1u);
+                kv[q][i] = ci.keys[min(at, last)];
+            }
         }
-        if (go1) {
-            if (k1 < key1)
-                lo1 = m1 + 1;
-            else
-                hi1 = m1;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t len = hi[q] - lo[q];
+            int c = 0;  // loaded entries below the key: a prefix, the keys being sorted
+#pragma unroll
+            for (int i = 0; i < 7; i++) c += ((int64_t)kv[q][i] < key[q] && (len > 7u || (uint32_t)i < len)) ? 1 : 0;
+            // pivot i sits at lo + (i + 1) * step - 1; the answer lies behind the last pivot below the key
+            // and not behind the first one at or above it
+            const uint32_t base = lo[q];
+            const uint32_t hi_few = base + (uint32_t)c, lo_few = hi_few;
+            const uint32_t hi_many = c < 7 ? base + (uint32_t)(c + 1) * step[q] - 1u : hi[q];
+            const uint32_t lo_many = c > 0 ? base + (uint32_t)c * step[q] : base;
+            hi[q] = len == 0 ? hi[q] : (len <= 7u ? hi_few : hi_many);
+            lo[q] = len == 0 ? lo[q] : (len <= 7u ? lo_few : lo_many);
         }
     }
-    b = lo0;
-    e = lo1;
+    b = lo[0];
+    e = lo[1];
 }
 
 enum Mode { M_KNN = 0, M_SOR = 1, M_NORMALS = 2, M_NNDIST = 3, M_COUNT = 4, M_ALL = 5 };

@@ -255,27 +255,26 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                         uint32_t jj[AHEAD];
                         double px[AHEAD], py[AHEAD], pz[AHEAD];
                         int32_t pid[AHEAD];
+                        // where the AHEAD batches' records are ...
 #pragma unroll
                         for (int u = 0; u < AHEAD; u++) {
                             const uint32_t tf = t0 + u * PC_WAVE, t = tf + lane;
-                            jj[u] = 0;
-                            px[u] = py[u] = pz[u] = 0.0;
-                            pid[u] = 0;
-                            if (tf >= limit) continue;  // uniform
-                            while (cur + 1 < nrows && row_off[cur + 1] <= tf) cur++;
+                            if (tf < limit)  // uniform
+                                while (cur + 1 < nrows && row_off[cur + 1] <= tf) cur++;
                             const bool one_row = cur + 1 >= nrows || row_off[cur + 1] > tf + (PC_WAVE - 1);
-                            if (t < limit) {
-                                int at = cur;
-                                if (!one_row) {
-                                    at = 0;  // the last row that starts at or before candidate t (rows of no length start where the next does)
+                            int at = cur;
+                            if (!one_row) {  // uniform
+                                at = 0;  // the last row that starts at or before candidate t (rows of no length start where the next does)
 #pragma unroll
-                                    for (int step = ROW_CACHE / 2; step > 0; step >>= 1)
-                                        if (at + step < nrows && row_off[at + step] <= t) at += step;
-                                }
-                                jj[u] = row_b[at] + (t - row_off[at]);
-                                RecTraits<REC>::load(rec + jj[u], px[u], py[u], pz[u], pid[u]);
+                                for (int step = ROW_CACHE / 2; step > 0; step >>= 1)
+                                    at += (at + step < nrows && row_off[min(at + step, ROW_CACHE)] <= t) ? step : 0;
                             }
+                            jj[u] = t < limit ? row_b[at] + (t - row_off[at]) : 0u;
                         }
+                        // ... then the loads, back to back with no branch between or around them (lanes past the
+                        // end read record 0 and drop it): they are in flight together and waited for once
+#pragma unroll
+                        for (int u = 0; u < AHEAD; u++) RecTraits<REC>::load(rec + jj[u], px[u], py[u], pz[u], pid[u]);
 #pragma unroll
                         for (int u = 0; u < AHEAD; u++) {
                             if (t0 + u * PC_WAVE >= limit || overflow) break;
