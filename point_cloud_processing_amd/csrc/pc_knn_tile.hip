@@ -411,7 +411,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     const bool hinted = qflag != nullptr && !A.qrec && A.radius2 < 0.0 && batch_passes && ks <= batch_max_ks &&
                         !getenv("PC_AMD_NO_HINTS");
     A.flag_top = hinted ? nlv : 0;
-    uint32_t *open_counter = A.flag_count + 28;
+    uint32_t *open_counter = A.flag_count + 29;  // (24..28: counters of instrumented builds)
     int64_t open_all = 0;
     for (int i = 0; i < nlv; i++) {
         const pc_grid *l = lv[i];

@@ -21,40 +21,12 @@ constexpr int MAX_TILE_WAVES = 4;  // waves of one workgroup, all working on the
 constexpr int UNEVEN_CAP = 1024;   // candidate capacity of the tiles of multi-level indexes
 constexpr int SEL_SLOTS = 16; // parked keys per lane between two sorted insertions
 
-// LDS reads whose pairing and issue point the compiler must not rearrange.  The values are valid only
-// after lds_wait(), which is tied to them through its operands.
-__device__ inline void lds_read_xyz_pair(uint32_t addr, f32x2 &x, f32x2 &y, f32x2 &z) {
-    asm volatile(
-        "ds_read2_b32 %0, %3 offset1:3\n\t"
-        "ds_read2_b32 %1, %3 offset0:1 offset1:4\n\t"
-        "ds_read2_b32 %2, %3 offset0:2 offset1:5"
-        : "=&v"(x), "=&v"(y), "=&v"(z)
-        : "v"(addr));
-}
-__device__ inline void lds_wait(f32x2 &x, f32x2 &y, f32x2 &z) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(y), "+v"(z));
-}
-__device__ inline uint32_t lds_read_u32(uint32_t addr) {
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
+// LDS reads by byte address.  Plain loads: the compiler places the waits, and nothing it moves or copies can
+// hold a value that has not arrived yet.  (A read issued in one asm statement and waited for in another looks
+// finished to the compiler in between; a register copy put there once returned the previous kernel's data.)
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
-__device__ inline uint32_t lds_read_u16(uint32_t addr) {
-    uint32_t v;
-    asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-// (ties the wait to the eighteen values it makes valid)
-__device__ inline void lds_wait(uint32_t (&a)[9], uint32_t (&b)[9]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]));
-}
-__device__ inline void lds_write_u32(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v)); }
-// (the slot one row of the wave's area above `addr`)
-__device__ inline void lds_write_u32_next(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1 offset:256" : : "v"(addr), "v"(v)); }
-__device__ inline void lds_wait(uint32_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)); }
+__device__ inline uint32_t lds_read_u32(uint32_t addr) { return *(const lds_u32 *)(uintptr_t)addr; }
+__device__ inline uint32_t lds_read_u16(uint32_t addr) { return *(const lds_u16 *)(uintptr_t)addr; }
 
 // Maximum over the wave (uniform result): butterfly inside each row of 16 lanes with DPP
 // (pairs, quads, half rows, rows: no LDS traffic), then the four row results through SGPRs.
@@ -71,7 +43,9 @@ __device__ inline int wave_max_i32(int v) {
 // pair (j0, j0 + 1) against their query in packed fp32, build the keys and push them on their stack of
 // parked keys (always written to the slot above the stack, which then grows by one slot or not: no
 // branch), until every lane is through its segment or some lane's stack has reached wp_full.  nx/ny/nz
-// hold the pair requested last (the request for the next pair goes out as soon as this one is consumed).
+// hold the pair at `pa` on entry and on exit; inside, the request for the next pair goes out as soon as this
+// one is consumed, and the block leaves with nothing in flight, so that every register it hands back holds
+// what the compiler thinks it holds.
 // Written as one block because the compiler's version of the same loop spends a third of its instructions
 // on exec-mask bookkeeping.  Waits that gfx950 wants between dependent instructions are met by the order:
 // a packed-fp32 result is read two instructions later at the earliest (an LDS read or an independent add sits
@@ -115,6 +89,7 @@ __device__ inline void scan_pairs(uint32_t &j0, const uint32_t end, uint32_t &pa
         "v_cmpx_lt_u32 %[j0], %[end]\n\t"
         "s_cbranch_execnz 1b\n"
         "2:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
         "s_mov_b64 exec, %[saved]"
         : [j0] "+v"(j0), [pa] "+v"(pa), [wp] "+v"(wp), [nx] "+v"(nx), [ny] "+v"(ny), [nz] "+v"(nz), [saved] "=&s"(saved),
           [m0] "=&s"(m0)
@@ -432,26 +407,29 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         const uint32_t col_a = (uint32_t)(uintptr_t)col;                   // LDS byte address of the column
         uint32_t wp = col_a - 4u * PC_WAVE;                                // last written slot (byte address)
         auto drain = [&](const uint32_t rounds) {  // (rounds: the same for all lanes)
+            // eight slots at a time, top down: the eight reads go out together (slots below the column's first
+            // are read too -- the tables in front of the columns, at least 4 KB of them -- and not used)
             uint32_t ra = wp;
-            uint32_t nxt = lds_read_u32(ra);  // (an empty stack reads the row in front of its column: not used)
-            bool valid = ra >= col_a;
 #pragma nounroll
-            for (uint32_t r = 0; r < rounds; r++) {
-                lds_wait(nxt);
-                const uint32_t key = valid ? nxt : KEY_EMPTY;
-                ra -= 4u * PC_WAVE;
-                nxt = lds_read_u32(ra);  // one slot ahead
-                list_insert<KS>(L, key);
-                valid = ra >= col_a;
+            for (uint32_t r0 = 0; r0 < rounds; r0 += DRAIN_ROUNDS) {
+                uint32_t key[DRAIN_ROUNDS];
+#pragma unroll
+                for (uint32_t i = 0; i < DRAIN_ROUNDS; i++) key[i] = lds_read_u32(ra - i * 4u * PC_WAVE);
+#pragma unroll
+                for (uint32_t i = 0; i < DRAIN_ROUNDS; i++) {
+                    if (r0 + i < rounds) {  // uniform
+                        list_insert<KS>(L, ra - i * 4u * PC_WAVE >= col_a ? key[i] : KEY_EMPTY);
 #ifdef PC_COUNT
-                n_rounds++;
+                        n_rounds++;
 #endif
+                    }
+                }
+                ra -= min(rounds - r0, DRAIN_ROUNDS) * 4u * PC_WAVE;
             }
-            lds_wait(nxt);
 #ifdef PC_COUNT
             n_drains++;
 #endif
-            wp = valid ? ra : col_a - 4u * PC_WAVE;
+            wp = ra >= col_a ? ra : col_a - 4u * PC_WAVE;
             thr = min(L[KS - 1], thr0);
         };
         int qc[3];
@@ -535,7 +513,6 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 st[seg] = lds_read_u16(ok ? a_st + off : a_st);
                 en[seg] = lds_read_u16(ok ? a_en + off : a_st);
             }
-            lds_wait(st, en);
 #pragma unroll
             for (int seg = 0; seg < 9; seg++) seg_pack[seg] = (st[seg] & 0xffffu) | ((en[seg] - st[seg]) << 16);
         }
@@ -592,8 +569,10 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             uint32_t j0 = seg_pack[seg] & 0xffffu;
             const uint32_t end = j0 + (seg_pack[seg] >> 16);
             uint32_t pa = cand_a + 12u * j0;
-            f32x2 nx, ny, nz;
-            lds_read_xyz_pair(pa, nx, ny, nz);
+            // (the first pair by plain loads; the candidate block is followed by two sentinels, so a pair
+            // behind the last candidate is readable)
+            const lds_f32 *const cp = (const lds_f32 *)(uintptr_t)pa;
+            f32x2 nx = {cp[0], cp[3]}, ny = {cp[1], cp[4]}, nz = {cp[2], cp[5]};
             for (;;) {
                 scan_pairs(j0, end, pa, wp, nx, ny, nz, qx2, qy2, qz2, thr, wp_full);
                 // (all lanes are back together here: the drain serves the whole wave, also the lanes whose
@@ -601,7 +580,6 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 if (__any(wp >= wp_full)) drain(DRAIN_ROUNDS);
                 if (!__any(j0 < end)) break;
             }
-            lds_wait(nx, ny, nz);  // retire the last (unused) request
 #ifdef PC_COUNT
             n_lock += (uint32_t)wave_max_i32((int)n_steps);
             n_steps = 0;
