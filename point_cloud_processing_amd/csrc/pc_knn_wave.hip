@@ -46,15 +46,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         const double qv[3] = {qx, qy, qz};
         int cnt = 0, lvl = 0, R = 1;
         bool spilled = false, jumped = false;
-#ifdef PC_WAVE_DEBUG
-        const unsigned long long dbg_t0 = wall_clock64();
-        unsigned long long dbg_cand = 0;
-        int dbg_steps = 0;
-        unsigned long long dbg_sec[5] = {0, 0, 0, 0, 0}, dbg_mark = dbg_t0;
-#define DBG_LAP(i) { const unsigned long long now_ = wall_clock64(); dbg_sec[i] += now_ - dbg_mark; dbg_mark = now_; }
-#else
-#define DBG_LAP(i)
-#endif
         // The finest level and ring whose block holds everything within sqrt(bound2) of the query: the ring
         // reaches R cells beyond the query's own cell on every side, i.e. at least R * cell.
         auto jump = [&](double bound2) -> bool {
@@ -169,15 +160,9 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 __syncthreads();
                 return total;
             };
-            DBG_LAP(0)
             uint32_t total = build_rows();
-            DBG_LAP(1)
 
             bool certified = false;
-#ifdef PC_WAVE_DEBUG
-            dbg_steps++;
-            if (total >= (uint32_t)k || can_end_short) dbg_cand += total;
-#endif
             if (total >= (uint32_t)k || can_end_short) {
                 // ---- survivors: candidates not farther than the bound, compacted into LDS ---------------
                 // Thinning inside LDS: the k-th smallest of ANY 64 held survivors bounds the true k-th
@@ -317,7 +302,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     }
                 }
                 __syncthreads();
-                DBG_LAP(2)
                 if (overflow) {
                     spilled = true;
                     break;
@@ -341,7 +325,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     }
                 }
                 __syncthreads();
-                DBG_LAP(3)
                 cnt = (int)min(mm, (uint32_t)k);
                 const double kth = cnt == k ? res_d[k - 1] : INFINITY;
                 __syncthreads();
@@ -388,20 +371,6 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 R++;
             }
         }
-#ifdef PC_WAVE_DEBUG
-        if (lane == 0) {
-            const unsigned long long dt = wall_clock64() - dbg_t0;  // 100 MHz ticks
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(A.flag_count + 40);
-            atomicAdd(dbg + 0, dt);
-            atomicMax(dbg + 1, dt);
-            atomicAdd(dbg + 2, dbg_cand);
-            atomicMax(dbg + 3, dbg_cand);
-            atomicAdd(dbg + 4, (unsigned long long)dbg_steps);
-            atomicMax(dbg + 5, (unsigned long long)dbg_steps);
-            for (int i = 0; i < 5; i++) atomicAdd(dbg + 6 + i, dbg_sec[i]);
-            atomicAdd(dbg + 11, wall_clock64() - dbg_mark);
-        }
-#endif
         if (spilled && lane == 0) {
             const uint32_t p = atomicAdd(A.flag2_count, 1u);
             if (p < A.flag_cap) A.flag2_list[p] = (int32_t)spos;
@@ -454,17 +423,5 @@ int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs
     else
         launch_wave<Rec64>(mode, nb, st, A);
     PC_HIP(hipGetLastError());
-#ifdef PC_WAVE_DEBUG
-    {
-        unsigned long long h[12];
-        hipStreamSynchronize(st);
-        hipMemcpy(h, A.flag_count + 40, sizeof(h), hipMemcpyDeviceToHost);
-        unsigned int nqh = 0;
-        hipMemcpy(&nqh, A.qcount, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[wave] queries %u: ticks sum %llu max %llu, cand sum %llu max %llu, steps sum %llu max %llu; sections setup/rows/scan/rank/-/tail", nqh, h[0], h[1], h[2], h[3], h[4], h[5]);
-        for (int i = 0; i < 6; i++) fprintf(stderr, " %llu", h[6 + i]);
-        fprintf(stderr, "\n");
-    }
-#endif
     return PC_OK;
 }
