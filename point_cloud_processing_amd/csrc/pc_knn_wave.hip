@@ -271,6 +271,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 // row first -- give a bound, the rows are cut again under it, and so on while that still removes
                 // a quarter of the block.  (A stray point next to a cluster: 185 000 candidates in its first
                 // block with k points, 2.7 ms for one wave to look at them all.)
+                bool moved = false;  // the probe's bound asked for a block on a finer level
                 for (int probe = 0; probe < 6 && flat && total > PROBE_MIN && !can_end_short; probe++) {
                     const double ub0 = ub;
                     scan_flat(PROBE_LEN);
@@ -280,10 +281,24 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                     overflow = false;
                     if (!(ub < ub0)) break;  // nothing learned
                     pb = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;
+                    if (!jumped) {
+                        // first bound of this query: cells of this level may be far wider than the bound (a stray
+                        // point whose first block with k points spans a whole cluster) -- then the block that
+                        // certifies lies on a finer level, where cutting rows by the bound means something
+                        const int l0 = lvl, r0 = R;
+                        if (jump(pb) && lvl < l0) {
+                            jumped = true;
+                            moved = true;
+                            break;
+                        }
+                        lvl = l0;
+                        R = r0;
+                    }
                     const uint32_t before = total;
                     total = build_rows();
                     if (4ull * total > 3ull * before) break;
                 }
+                if (moved) continue;
                 if (flat) {
                     scan_flat(total);
                 } else {
