@@ -51,7 +51,10 @@ enum pc_status {
 /* Largest k accepted by the neighbour searches. */
 #define PC_MAX_K 64
 
-/* ---- context ---------------------------------------------------------------------------- */
+/* ---- context ----------------------------------------------------------------------------
+ * pc_create also reads the library's tuning and diagnosis switches from the environment (PC_AMD_DEBUG and the
+ * PC_AMD_* knobs named in csrc/pc_common.h, struct PcKnobs), once, into the context: later changes of the
+ * environment do not reach a context that exists already, and no other entry point looks at the environment. */
 int pc_create(int device, pc_ctx **out);
 void pc_destroy(pc_ctx *ctx);
 const char *pc_last_error(const pc_ctx *ctx);

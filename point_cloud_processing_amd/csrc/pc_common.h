@@ -14,6 +14,29 @@ constexpr int MAX_FINER = 3;   // grids of half the cell edge each, made for the
 
 #define PC_WAVE 64  // gfx950 wavefront width (hard-coded: not a host compile-time constant)
 
+// Tuning and diagnosis switches of the environment (PC_AMD_*), read once, when a context is created, and kept
+// with it: no call on the hot path looks at the environment.
+struct PcKnobs {
+    bool debug = false;            // PC_AMD_DEBUG: per-pass log on stderr
+    double cell_scale = 0.0;       // PC_AMD_CELL_SCALE: scales the automatic cell edge (0: off)
+    bool no_halves = false;        // PC_AMD_NO_HALVES
+    int uneven_cap = 0;            // PC_AMD_UNEVEN_CAP: candidates an uneven level's tile stages (0: default)
+    int tile_waves = 0;            // PC_AMD_TILE_WAVES (0: default)
+    int tile[3] = {0, 0, 0};       // PC_AMD_TILE "tx,ty,tz" (0: automatic)
+    int uneven_tile0 = 0, uneven_tile1 = 0;  // PC_AMD_UNEVEN_TILE0 / _TILE1 (0: default)
+    int uneven_waves = 0;          // PC_AMD_UNEVEN_WAVES (0: default)
+    bool exact_scan_only = false;  // PC_AMD_EXACT_SCAN_ONLY: one-query-per-lane fp64 scan only (A/B switch)
+    bool no_batch = false;         // PC_AMD_NO_BATCH
+    int batch_ks = 34;             // PC_AMD_BATCH_KS
+    int64_t batch_ratio = 12;      // PC_AMD_BATCH_RATIO
+    bool no_hints = false;         // PC_AMD_NO_HINTS
+    bool no_mixed = false;         // PC_AMD_NO_MIXED
+    int64_t mixed_min = 1ll << 20; // PC_AMD_MIXED_MIN
+    uint32_t full_tile = 32;       // PC_AMD_FULL_TILE
+    bool no_finer = false;         // PC_AMD_NO_FINER
+};
+PcKnobs pc_read_knobs();
+
 struct pc_ctx {
     int device = 0;
     // grow-only cache of device blocks so that per-frame calls do not hipMalloc
@@ -33,6 +56,7 @@ struct pc_ctx {
     // another stream waits for the previous one first.
     hipStream_t last_stream = nullptr;
     bool has_last_stream = false;
+    PcKnobs knobs;  // the environment's switches as pc_create found them
 
     void *alloc(size_t bytes);
     void release(void *p);
@@ -40,6 +64,8 @@ struct pc_ctx {
 };
 
 int pc_fail(pc_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+
+
 
 struct PcLock {
     pc_ctx *c;

@@ -62,6 +62,40 @@ void pc_ctx::trim() {
     pool.swap(keep);
 }
 
+PcKnobs pc_read_knobs() {
+    {
+        PcKnobs k;
+        auto on = [](const char *name) { return getenv(name) != nullptr; };
+        auto num = [](const char *name, long long dflt) {
+            const char *e = getenv(name);
+            return e ? atoll(e) : dflt;
+        };
+        k.debug = on("PC_AMD_DEBUG");
+        if (const char *e = getenv("PC_AMD_CELL_SCALE")) k.cell_scale = atof(e);
+        k.no_halves = on("PC_AMD_NO_HALVES");
+        k.uneven_cap = (int)num("PC_AMD_UNEVEN_CAP", 0);
+        k.tile_waves = (int)num("PC_AMD_TILE_WAVES", 0);
+        if (const char *e = getenv("PC_AMD_TILE")) {
+            int v[3];
+            if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3)
+                for (int a = 0; a < 3; a++) k.tile[a] = v[a];
+        }
+        k.uneven_tile0 = (int)num("PC_AMD_UNEVEN_TILE0", 0);
+        k.uneven_tile1 = (int)num("PC_AMD_UNEVEN_TILE1", 0);
+        k.uneven_waves = (int)num("PC_AMD_UNEVEN_WAVES", 0);
+        k.exact_scan_only = on("PC_AMD_EXACT_SCAN_ONLY");
+        k.no_batch = on("PC_AMD_NO_BATCH");
+        k.batch_ks = (int)num("PC_AMD_BATCH_KS", 34);
+        k.batch_ratio = num("PC_AMD_BATCH_RATIO", 12);
+        k.no_hints = on("PC_AMD_NO_HINTS");
+        k.no_mixed = on("PC_AMD_NO_MIXED");
+        k.mixed_min = num("PC_AMD_MIXED_MIN", 1ll << 20);
+        k.full_tile = (uint32_t)num("PC_AMD_FULL_TILE", 32);
+        k.no_finer = on("PC_AMD_NO_FINER");
+        return k;
+    }
+}
+
 extern "C" {
 
 int pc_abi_version(void) { return 1; }
@@ -96,6 +130,7 @@ int pc_create(int device, pc_ctx **out) {
         delete c;
         return PC_HIP_ERROR;
     }
+    c->knobs = pc_read_knobs();  // the environment is read here, once per context
     *out = c;
     return PC_OK;
 }
@@ -788,8 +823,8 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         for (int a = 0; a < 3; a++) vol *= std::max(ext[a], emax * 1e-3);
         cell = (n > 0 && vol > 0) ? cbrt(vol * target / (double)n) : 1.0;
         if (!(cell > 0) || !std::isfinite(cell)) cell = 1.0;
-        if (const char *e = getenv("PC_AMD_CELL_SCALE")) {  // tuning knob: scales the automatic edge
-            const double f = atof(e);
+        {   // tuning knob: scales the automatic edge
+            const double f = ctx->knobs.cell_scale;
             if (f > 0.1 && f < 10.0) cell *= f;
         }
     }
@@ -835,7 +870,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
             // (not for the nearly empty cells of k <= 2: nothing to gain from halving one or two points)
             const int halfbit = (!parent && automatic && dense && dtype == PC_F32 && g->ncell < (1ll << 31) && k_hint > 2 &&
-                                 !getenv("PC_AMD_NO_HALVES")) ? 1 : 0;
+                                 !ctx->knobs.no_halves) ? 1 : 0;
             g->halves = halfbit != 0;
             if (parent && dtype == PC_F32)
                 hipLaunchKernelGGL(k_cell_keys32_rec<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
@@ -905,7 +940,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
             g->seen = seen;
-            if (getenv("PC_AMD_DEBUG") && automatic)
+            if (ctx->knobs.debug && automatic)
                 fprintf(stderr, "[pc_amd]   grid attempt %d: cell %.4g cells %lld occupied %lld seen %.1f (target %.1f)\n", attempt,
                         cell, (long long)g->ncell, (long long)g->occupied, seen, target);
             if (!automatic || attempt >= 8) break;

@@ -179,7 +179,7 @@ int launch_scan(pc_ctx *ctx, const pc_grid *g, int qdtype, const ScanArgs &A0, h
             hipLaunchKernelGGL((k_scan<Rec64, double, MODE>), dim3(nb), dim3(PC_WAVE), lds, st, A);
     }
     PC_HIP(hipGetLastError());
-    if (tiled && getenv("PC_AMD_DEBUG")) {  // development aid: how many queries each re-run stage received
+    if (tiled && ctx->knobs.debug) {  // development aid: how many queries each re-run stage received
         uint32_t c[32];
         PC_HIP(hipStreamSynchronize(st));
         PC_HIP(hipMemcpy(c, A.flag_count, sizeof(c), hipMemcpyDeviceToHost));

@@ -134,8 +134,8 @@ int build_tile_list_dense(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
 }
 
 // candidates an uneven level's tile stages (tuning knob: PC_AMD_UNEVEN_CAP)
-int uneven_cap() {
-    if (const char *e = getenv("PC_AMD_UNEVEN_CAP")) return std::min(CAND_CAP_MAX, std::max(256, atoi(e) / 64 * 64));
+int uneven_cap(const pc_ctx *ctx) {
+    if (const int e = ctx->knobs.uneven_cap) return std::min(CAND_CAP_MAX, std::max(256, e / 64 * 64));
     return UNEVEN_CAP;
 }
 
@@ -226,7 +226,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
         // expected population (plus 1.5 sigma) still fits the workgroup's lanes; among equals the one
         // with the smallest block.
         waves = MAX_TILE_WAVES;  // measured at 10 M, k = 16: 4 waves 2.78 ms, 2 waves 3.27 ms (LDS-bound occupancy)
-        if (const char *e = getenv("PC_AMD_TILE_WAVES")) waves = std::min(MAX_TILE_WAVES, std::max(1, atoi(e)));
+        if (const int e = ctx->knobs.tile_waves) waves = std::min(MAX_TILE_WAVES, std::max(1, e));
         double best_pop = -1.0, best_block = 0.0;
         for (int tz = 1; tz <= 6; tz++)
             for (int ty = 1; ty <= 6; ty++)
@@ -247,10 +247,9 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
                         best[2] = tz;
                     }
                 }
-        if (const char *e = getenv("PC_AMD_TILE")) {  // tuning knob: "tx,ty,tz"
-            int v[3];
-            if (sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] >= 1 && v[0] + 2 <= MAX_NX && v[1] >= 1 && v[2] >= 1 &&
-                (v[1] + 2) * (v[2] + 2) <= MAX_ROWS) {
+        {   // tuning knob: "tx,ty,tz"
+            const int *v = ctx->knobs.tile;
+            if (v[0] >= 1 && v[0] + 2 <= MAX_NX && v[1] >= 1 && v[2] >= 1 && (v[1] + 2) * (v[2] + 2) <= MAX_ROWS) {
                 for (int a = 0; a < 3; a++) best[a] = std::min(v[a], std::max(1, (int)g->gp.dim[a]));
                 best_pop = occ * best[0] * best[1] * best[2];
             }
@@ -266,9 +265,9 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
         // levels, whose open points sit in fuller cells) and grow it while the occupied tiles hold
         // too few points to fill a wave (thin surfaces, scan lines); the shape is settled below.
         int base = g->level > 0 ? 1 : 2;
-        if (const char *e = getenv(g->level > 0 ? "PC_AMD_UNEVEN_TILE1" : "PC_AMD_UNEVEN_TILE0")) base = std::max(1, atoi(e));
+        if (const int e = g->level > 0 ? ctx->knobs.uneven_tile1 : ctx->knobs.uneven_tile0) base = std::max(1, e);
         for (int a = 0; a < 3; a++) best[a] = std::min(std::min(base, a == 0 ? MAX_NX - 2 : 6), std::max(1, (int)g->gp.dim[a]));
-        expect = uneven_cap();
+        expect = uneven_cap(ctx);
         waves = 1;  // (passes over few tiles take two: uneven_waves below)
     }
     int cap = ((int)expect + 63) / 64 * 64;
@@ -290,7 +289,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
         // planes + clutter, 26 M queries answered at level 2: 116 -> 52 ms for that pass.  Small clouds and
         // surfaces lose with the bigger tile, hence the thresholds.)
         if (grow == 0 && g->level > 0 && g->tile[0] == 1 && listed >= (1ll << 20) && listed >= 8 * std::max<int64_t>(1, g->occupied) &&
-            !getenv("PC_AMD_UNEVEN_TILE1")) {
+            !ctx->knobs.uneven_tile1) {
             ctx->release(g->tile_list);
             g->tile_list = nullptr;
             g->tile_count = 0;
@@ -322,8 +321,8 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
 // a LiDAR sensor) set the length of the pass and a second wave halves it (config 3 frame: 2.21 -> 1.94 ms);
 // with many tiles the GPU is full either way and the second wave only costs LDS (66 M voxels of planes +
 // clutter: 304 -> 326 ms).  Four waves measured slower everywhere.
-int uneven_waves(int64_t tiles) {
-    if (const char *e = getenv("PC_AMD_UNEVEN_WAVES")) return std::min(MAX_TILE_WAVES, std::max(1, atoi(e)));
+int uneven_waves(const pc_ctx *ctx, int64_t tiles) {
+    if (const int e = ctx->knobs.uneven_waves) return std::min(MAX_TILE_WAVES, std::max(1, e));
     return tiles < 32768 ? 2 : 1;
 }
 
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled) {
     *handled = false;
     if (A.queries != nullptr || A.k > 50 || mode == M_COUNT || A.nq <= 0) return PC_OK;
-    if (getenv("PC_AMD_EXACT_SCAN_ONLY")) return PC_OK;  // A/B switch: one-query-per-lane fp64 scan only
+    if (ctx->knobs.exact_scan_only) return PC_OK;  // A/B switch: one-query-per-lane fp64 scan only
     // the levels of the index, finest first; every level gets a tile pass, a coarser one answering
     // only what the finer ones flagged
     const pc_grid *lv[MAX_LEVELS];
@@ -390,13 +389,14 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         PC_HIP(hipMemsetAsync(qflag, 0, npt, st));
     }
     // coarser levels: a tile pass per occupied tile, or the open queries dealt 64 to a wave
-    const bool batch_passes = getenv("PC_AMD_NO_BATCH") == nullptr;
+    const PcKnobs &knobs = ctx->knobs;
+    const bool batch_passes = !knobs.no_batch;
     int64_t open_prev = 0;  // queries still open after the previous pass
     const int64_t batch_min = 65536;
     int list_level = -1, binned_level = 0;  // the level open_list / qrec_l were made for
     int64_t list_count = 0;
-    const int batch_max_ks = getenv("PC_AMD_BATCH_KS") ? atoi(getenv("PC_AMD_BATCH_KS")) : 34;
-    const int64_t batch_ratio = getenv("PC_AMD_BATCH_RATIO") ? atoi(getenv("PC_AMD_BATCH_RATIO")) : 12;
+    const int batch_max_ks = knobs.batch_ks;
+    const int64_t batch_ratio = knobs.batch_ratio;
     const int ks = A.k <= 2 ? 4 : (A.k <= 8 ? 10 : (A.k <= 16 ? 18 : (A.k <= 20 ? 22 : (A.k <= 32 ? 34 : 52))));
     // external queries arrive binned into level 0; a coarser level bins them again into its own cells
     const void *qrec0 = A.qrec;
@@ -409,7 +409,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // and no pass before that level lists the query.  (66 M voxels of planes + clutter: the 29 M clutter
     // points, answered at level 2, no longer ride through a pass at level 1 that can only look up their cells.)
     const bool hinted = qflag != nullptr && !A.qrec && A.radius2 < 0.0 && batch_passes && ks <= batch_max_ks &&
-                        !getenv("PC_AMD_NO_HINTS");
+                        !knobs.no_hints;
     A.flag_top = hinted ? nlv : 0;
     uint32_t *open_counter = A.flag_count + 29;  // (24..28: counters of instrumented builds)
     int64_t open_all = 0;
@@ -464,9 +464,9 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         bool mixed = false;
         // (Measured: 66 M voxels of planes + clutter, k = 32: 348 -> 304 ms; thresholds of 16 to 64 points per
         // full tile alike.  Small clouds would pay more for the two extra read-backs than they gain.)
-        if (batch && i == 0 && !A.qrec && l->tile_list && !getenv("PC_AMD_NO_MIXED") &&
-            l->n >= (getenv("PC_AMD_MIXED_MIN") ? atoll(getenv("PC_AMD_MIXED_MIN")) : (1ll << 20))) {
-            const uint32_t thresh = getenv("PC_AMD_FULL_TILE") ? (uint32_t)atoi(getenv("PC_AMD_FULL_TILE")) : 32u;
+        if (batch && i == 0 && !A.qrec && l->tile_list && !knobs.no_mixed &&
+            l->n >= knobs.mixed_min) {
+            const uint32_t thresh = knobs.full_tile;
             PC_TRY(build_full_tiles(ctx, l, thresh, st));
             mixed = l->full_count > 0 && l->full_points >= l->n / 4;
         }
@@ -509,12 +509,12 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             // largest block keeps them whole -- 66 M voxels of planes + clutter, 137 points per full tile: 72 ->
             // 60 ms for this pass.  Thinner ones only lose LDS occupancy to it: 4 M points, 79 per full tile,
             // 16.5 -> 17.5 ms for the whole search.)
-            if (!getenv("PC_AMD_UNEVEN_CAP") && l->full_points >= 100 * l->full_count) A.cand_cap = CAND_CAP_MAX;
-            const int nw = uneven_waves(f1 - f0);
+            if (!knobs.uneven_cap && l->full_points >= 100 * l->full_count) A.cand_cap = CAND_CAP_MAX;
+            const int nw = uneven_waves(ctx, f1 - f0);
             const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (3 * MAX_ROWS + 4) +
                                (A.halves ? 2 : 1) * sizeof(uint16_t) * MAX_ROWS * (MAX_NX + 1) +
                                nw * std::max(sizeof(uint32_t) * PC_WAVE * (SEL_SLOTS + 1), sizeof(uint16_t) * PC_WAVE * (size_t)A.k);
-            if (getenv("PC_AMD_DEBUG"))
+            if (knobs.debug)
                 fprintf(stderr, "[pc_amd]   full-tile pass 0: %lld of %lld tiles, %lld of %lld points\n", (long long)l->full_count,
                         (long long)l->tile_count, (long long)l->full_points, (long long)l->n);
             if (f1 <= f0) {
@@ -528,7 +528,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.count_crowded = 1;
             int64_t nopen = 0;
             PC_TRY(pc_batch_open_list(ctx, g->dtype, l->rec, l->n, qflag, A.flag_max, open_list, &nopen, &open_all, open_counter, st));
-            if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass 0: %lld open queries\n", (long long)nopen);
+            if (knobs.debug) fprintf(stderr, "[pc_amd]   batch pass 0: %lld open queries\n", (long long)nopen);
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
         } else if (batch) {
             int64_t nopen = A.nq;
@@ -537,14 +537,14 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             else if (i > 0)
                 PC_TRY(pc_batch_open_list(ctx, g->dtype, A.qrec ? A.qrec : l->rec, A.qrec ? A.nq : l->n, qflag, A.flag_max, open_list,
                                           &nopen, &open_all, open_counter, st));
-            if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   batch pass %d: %lld open queries\n", i, (long long)nopen);
+            if (knobs.debug) fprintf(stderr, "[pc_amd]   batch pass %d: %lld open queries\n", i, (long long)nopen);
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, i > 0 ? open_list : nullptr, nopen, st));
         } else if (hinted && i > 0 && list_level == i && list_count == 0) {
             // (no open query starts at or before this level)
         } else {
             if (nt <= 0) continue;
-            const int nw = l->uneven ? uneven_waves(nt) : std::max(1, l->tile_waves);
-            if (getenv("PC_AMD_DEBUG"))
+            const int nw = l->uneven ? uneven_waves(ctx, nt) : std::max(1, l->tile_waves);
+            if (knobs.debug)
                 fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],
                         l->tile[2], l->tile_cap, nw, (long long)nt);
             const size_t lds = sizeof(float) * 4 * ((size_t)A.cand_cap + 2) + sizeof(uint32_t) * (3 * MAX_ROWS + 4) +
@@ -580,7 +580,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             } else {
                 PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
             }
-            if (getenv("PC_AMD_DEBUG"))
+            if (knobs.debug)
                 fprintf(stderr, "[pc_amd]   level %d: cell %.4g dims %dx%dx%d tile %dx%dx%d cap %d tiles %lld sparse %d -> open %lld\n",
                         i, l->gp.cell, l->gp.dim[0], l->gp.dim[1], l->gp.dim[2], l->tile[0], l->tile[1], l->tile[2],
                         l->tile_cap, (long long)nt, l->keys != nullptr, (long long)open);
@@ -597,12 +597,12 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // of half the cell edge each, made on first need and kept with the index.  A pass costs little for
     // the isolated ones (their cells are nearly empty); going finer stops when it closes under 5 %.
     uint32_t crowded = 0;
-    if (qflag && batch_passes && !getenv("PC_AMD_NO_FINER") && open_prev >= std::max<int64_t>(2048, A.nq / 200)) {
+    if (qflag && batch_passes && !knobs.no_finer && open_prev >= std::max<int64_t>(2048, A.nq / 200)) {
         uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pinned);
         PC_HIP(hipMemcpyAsync(h, A.flag_count + 26, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PC_HIP(hipStreamSynchronize(st));
         crowded = h[0];  // queries the FIRST pass found amid more candidates than a tile stages
-        if (getenv("PC_AMD_DEBUG")) fprintf(stderr, "[pc_amd]   %lld open after the ladder, %u crowded in the first pass\n", (long long)open_prev, crowded);
+        if (knobs.debug) fprintf(stderr, "[pc_amd]   %lld open after the ladder, %u crowded in the first pass\n", (long long)open_prev, crowded);
     }
     if (crowded >= std::max<int64_t>(2048, A.nq / 100)) {
         const pc_grid *fine = g;
@@ -619,7 +619,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.gp = fine->gp;
             A.rec = fine->rec;
             A.ci = fine->index();
-            A.cand_cap = uneven_cap();
+            A.cand_cap = uneven_cap(ctx);
             A.qflag_in = qflag;
             A.qflag_out = qflag;
             A.flag_max = 255;
@@ -629,7 +629,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                                       &open_all, open_counter, st));
             PC_TRY(pc_launch_batch_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, st));
             PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
-            if (getenv("PC_AMD_DEBUG"))
+            if (knobs.debug)
                 fprintf(stderr, "[pc_amd]   finer level: cell %.4g, %lld open queries -> %lld\n", fine->gp.cell, (long long)nopen,
                         (long long)open);
             const bool progress = nopen - open >= nopen / 20;

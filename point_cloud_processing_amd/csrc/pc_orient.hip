@@ -206,7 +206,7 @@ extern "C" int pc_orient_normals(pc_ctx *ctx, const void *xyz_dev, int dtype, do
     hipLaunchKernelGGL(k_orient_init, dim3(nbs), dim3(256), 0, st, normals_dev, knn_idx_dev, knn_cnt_dev, n, k,
                        wbits.as<uint32_t>(), link.as<uint32_t>());
     PC_HIP(hipGetLastError());
-    const bool debug = getenv("PC_AMD_DEBUG") != nullptr;
+    const bool debug = ctx->knobs.debug;
     for (int round = 0; round < 64; round++) {  // pieces at least halve per round: 31 would do
         PC_HIP(hipMemsetAsync(best.p, 0xFF, sizeof(unsigned long long) * (size_t)n, st));
         PC_HIP(hipMemsetAsync(cnt_dev, 0, sizeof(uint32_t), st));

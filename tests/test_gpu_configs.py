@@ -54,6 +54,13 @@ def test_config5_icp_correspondences_k1(hip, oracle):
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and (cnt == 1).all()
 
 
+def _engine_of_this_environment():
+    """A new engine: the library reads its PC_AMD_* switches when a context is created."""
+    from point_cloud_processing_amd.hip_engine import HipEngine
+
+    return HipEngine(0)
+
+
 def test_uneven_density_clusters(hip, oracle):
     """Density varying by orders of magnitude: every level of the index and the re-run kernels."""
     p = D.gaussian_clusters(300_000, 8)
@@ -69,7 +76,7 @@ def test_scan_paths_agree(hip, oracle, monkeypatch):
     p = D.bumpy_sphere(50_000, 9)
     a = hip.knn(p, None, 20, -1.0, {})
     monkeypatch.setenv("PC_AMD_EXACT_SCAN_ONLY", "1")
-    b = hip.knn(p, None, 20, -1.0, {})
+    b = _engine_of_this_environment().knn(p, None, 20, -1.0, {})
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
@@ -83,7 +90,8 @@ def test_level_passes_agree(hip, oracle, monkeypatch, k):
     q = (p[rng.permutation(len(p))[:60_000]] + rng.normal(0, 0.01, (60_000, 3))).astype(np.float32).astype(np.float64)
     a_self, a_ext = hip.knn(p, None, k, -1.0, {}), hip.knn(p, q, k, -1.0, {})
     monkeypatch.setenv("PC_AMD_NO_BATCH", "1")
-    b_self, b_ext = hip.knn(p, None, k, -1.0, {}), hip.knn(p, q, k, -1.0, {})
+    other = _engine_of_this_environment()
+    b_self, b_ext = other.knn(p, None, k, -1.0, {}), other.knn(p, q, k, -1.0, {})
     assert all(np.array_equal(x, y) for x, y in zip(a_self, b_self))
     assert all(np.array_equal(x, y) for x, y in zip(a_ext, b_ext))
     ridx, rd2, rcnt = oracle.knn(p, q, k)
@@ -119,6 +127,7 @@ def test_mixed_first_pass_agrees(hip, oracle, monkeypatch, k):
     monkeypatch.setenv("PC_AMD_MIXED_MIN", "0")
     monkeypatch.setenv("PC_AMD_FULL_TILE", "8")
     monkeypatch.setenv("PC_AMD_DEBUG", "1")
+    hip = _engine_of_this_environment()
     cache = {}
     idx, d2, cnt, avg, nrm = hip.knn_fused(p, k, -1.0, cache)
     assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
