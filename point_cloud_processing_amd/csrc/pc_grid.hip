@@ -862,6 +862,14 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         bool in_tmp = false, dense = true;
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
+        // Where smaller cells separate nothing -- as many occupied cells as before: the crowd in a cell is copies
+        // of one position (merged scans, coordinates quantised at a far origin) -- the previous, coarser edge is
+        // taken back: ever smaller cells would only put the next distinct position dozens of empty cells away
+        // (90 000 points on 1 100 positions: queries between the positions took seconds each in the ring scan).
+        int64_t prev_occupied = -1;
+        double prev_cell = cell;
+        int32_t prev_dim[3] = {g->gp.dim[0], g->gp.dim[1], g->gp.dim[2]};
+        bool settle = false;
         for (int attempt = 0; n > 0; attempt++) {
             g->gp.cell = cell;
             g->gp.s = 1.0 / cell;
@@ -943,8 +951,17 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             if (ctx->knobs.debug && automatic)
                 fprintf(stderr, "[pc_amd]   grid attempt %d: cell %.4g cells %lld occupied %lld seen %.1f (target %.1f)\n", attempt,
                         cell, (long long)g->ncell, (long long)g->occupied, seen, target);
-            if (!automatic || attempt >= 8) break;
+            if (!automatic || attempt >= 8 || settle) break;
             if (seen <= 2.0 * (target + 1.0)) break;
+            if (attempt > 0 && g->occupied <= prev_occupied + prev_occupied / 50) {
+                cell = prev_cell;
+                for (int a = 0; a < 3; a++) g->gp.dim[a] = prev_dim[a];
+                settle = true;
+                continue;
+            }
+            prev_occupied = g->occupied;
+            prev_cell = cell;
+            for (int a = 0; a < 3; a++) prev_dim[a] = g->gp.dim[a];
             int32_t dim2[3];
             const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
             const double got = fit_dims(want, dim2);
