@@ -135,32 +135,43 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 cell_range(ci, row + x0, row + x1 + 1, b, e);
                 len = e - b;
             };
-            // population of the block under the bound pb: lanes over rows (the index searches of all rows
-            // overlap here); the rows' begins and running counts go to LDS
-            auto build_rows = [&]() -> uint32_t {
+            // Rows [first, first + ROW_CACHE) of the block under the bound pb, lanes over rows (the index searches of
+            // all rows overlap here): their begins and running counts go to LDS when `keep`; returns their
+            // population.  A block of at most ROW_CACHE rows is one such chunk.
+            int crows = 0;  // rows of the chunk in LDS
+            auto build_rows = [&](int first, bool keep) -> uint32_t {
+                const int last = min(first + ROW_CACHE, nrows);
                 uint32_t total = 0;
-                for (int base = 0; base < nrows; base += PC_WAVE) {
+                for (int base = first; base < last; base += PC_WAVE) {
                     const int ri = base + lane;
                     uint32_t b = 0, len = 0;
-                    if (ri < nrows) row_range(ri, b, len);
+                    if (ri < last) row_range(ri, b, len);
                     uint32_t inc = len;
 #pragma unroll
                     for (int o = 1; o < PC_WAVE; o <<= 1) {
                         const uint32_t t = __shfl_up(inc, o, 64);
                         if (lane >= o) inc += t;
                     }
-                    if (flat && ri < nrows) {
-                        row_b[ri] = b;
-                        row_off[ri] = total + inc - len;
+                    if (keep && ri < last) {
+                        row_b[ri - first] = b;
+                        row_off[ri - first] = total + inc - len;
                     }
                     total += __shfl(inc, PC_WAVE - 1, 64);
                 }
                 total = __builtin_amdgcn_readfirstlane(total);
-                if (flat && lane == 0) row_off[nrows] = total;
-                __syncthreads();
+                if (keep) {
+                    crows = last - first;
+                    if (lane == 0) row_off[crows] = total;
+                    __syncthreads();
+                }
                 return total;
             };
-            uint32_t total = build_rows();
+            uint32_t total = 0;
+            if (flat) {
+                total = build_rows(0, true);
+            } else {
+                for (int first = 0; first < nrows; first += ROW_CACHE) total += build_rows(first, false);
+            }
 
             bool certified = false;
             if (total >= (uint32_t)k || can_end_short) {
@@ -245,14 +256,14 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                         for (int u = 0; u < AHEAD; u++) {
                             const uint32_t tf = t0 + u * PC_WAVE, t = tf + lane;
                             if (tf < limit)  // uniform
-                                while (cur + 1 < nrows && row_off[cur + 1] <= tf) cur++;
-                            const bool one_row = cur + 1 >= nrows || row_off[cur + 1] > tf + (PC_WAVE - 1);
+                                while (cur + 1 < crows && row_off[cur + 1] <= tf) cur++;
+                            const bool one_row = cur + 1 >= crows || row_off[cur + 1] > tf + (PC_WAVE - 1);
                             int at = cur;
                             if (!one_row) {  // uniform
                                 at = 0;  // the last row that starts at or before candidate t (rows of no length start where the next does)
 #pragma unroll
                                 for (int step = ROW_CACHE / 2; step > 0; step >>= 1)
-                                    at += (at + step < nrows && row_off[min(at + step, ROW_CACHE)] <= t) ? step : 0;
+                                    at += (at + step < crows && row_off[min(at + step, ROW_CACHE)] <= t) ? step : 0;
                             }
                             jj[u] = t < limit ? row_b[at] + (t - row_off[at]) : 0u;
                         }
@@ -295,25 +306,18 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                         R = r0;
                     }
                     const uint32_t before = total;
-                    total = build_rows();
+                    total = build_rows(0, true);
                     if (4ull * total > 3ull * before) break;
                 }
                 if (moved) continue;
                 if (flat) {
                     scan_flat(total);
                 } else {
-                    // more rows than LDS keeps (a large ring on the coarsest level): row by row
-                    for (int ri = 0; ri < nrows && !overflow; ri++) {
-                        uint32_t jv = 0, lv = 0;
-                        if (lane == 0) row_range(ri, jv, lv);
-                        const uint32_t jb = __builtin_amdgcn_readfirstlane(jv), je = jb + __builtin_amdgcn_readfirstlane(lv);
-                        for (uint32_t j0 = jb; j0 < je && !overflow; j0 += PC_WAVE) {
-                            const uint32_t j = j0 + lane;
-                            double px = 0.0, py = 0.0, pz = 0.0;
-                            int32_t pid = 0;
-                            if (j < je) RecTraits<REC>::load(rec + j, px, py, pz, pid);
-                            take(j < je, j, px, py, pz, pid);
-                        }
+                    // more rows than LDS keeps (a large ring on the coarsest level): a chunk of rows at a time
+                    for (int first = 0; first < nrows && !overflow; first += ROW_CACHE) {
+                        __syncthreads();  // the previous chunk's rows are done with
+                        const uint32_t ct = build_rows(first, true);
+                        scan_flat(ct);
                     }
                 }
                 __syncthreads();
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
             }
             // The next block.  With a bound: the block that certainly holds everything within it (it certifies;
             // should rounding at a cell face ever deny that, the ring grows from there).  Without one: ring 1
-            // at each level in turn (block edges 3, 6, 12, ... fine cells), then ever larger rings at the
-            // coarsest level.
+            // at each level in turn (block edges 3, 6, 12, ... fine cells), then rings half as wide again each
+            // time at the coarsest level.
             const double pbn = r2lim >= 0.0 ? fmin(ub, r2lim) : ub;
             if (jumped) {
                 R++;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
                 lvl++;
                 R = 1;
             } else {
-                R++;
+                R += max(1, R / 2);  // (no bound yet: half as far again; the first bound cuts the block back)
             }
         }
         if (spilled && lane == 0) {
