@@ -96,3 +96,55 @@ def test_shard_range_partitions():
             assert pos[0][0] == 0 and pos[-1][1] == n
             assert all(pos[i][1] == pos[i + 1][0] for i in range(w - 1))
             assert all(b % SOR_CHUNK == 0 for b, e in pos if e > b)
+
+
+# ---- the HIP engine in real processes ------------------------------------------------------------
+def _hip_worker(rank, world, port, out_dir, backend):
+    """One rank of a real process group with the production engine: every rank on cuda:0 (the test box has
+    one GPU; RCCL itself wants a GPU per rank, so the collective here is gloo's, on DEVICE tensors)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from point_cloud_processing_amd import distributed as PD
+        from point_cloud_processing_amd.hip_engine import HipEngine
+
+        eng = HipEngine(0)
+        pts = _cloud()
+        kept, stats = PD.sor_sharded(eng, pts, 20, 2.0)
+        nrm = PD.normals_sharded(eng, pts, 30, 0.01)
+        sh = PD.knn_sharded(eng, pts, 8)
+        host = lambda a: a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), kept=host(kept), stats=np.array(stats), nrm=host(nrm),
+                 owned=host(sh["owned"]), idx=host(sh["idx"]), d2=host(sh["d2"]), cnt=host(sh["cnt"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_engine_in_real_processes(hip, oracle, tmp_path, world):
+    """The sharded filter, normals and rows with the HIP engine in ``world`` real processes (device tensors
+    through the process group's all-reduce), against the single-process HIP result and the oracle."""
+    from point_cloud_processing_amd import distributed as PD
+
+    port = _free_port()
+    mp.spawn(_hip_worker, args=(world, port, str(tmp_path), "gloo"), nprocs=world, join=True)
+    pts = _cloud()
+    (kept1, stats1), = PD.run_emulated(lambda r: PD.sor_steps(hip, pts, 20, 2.0, {}, r, 1), 1)
+    kept1 = kept1.cpu().numpy() if hasattr(kept1, "cpu") else np.asarray(kept1)
+    rkept, _, rstats = oracle.sor(pts, 20, 2.0)
+    assert np.array_equal(kept1, rkept)
+    np.testing.assert_allclose(stats1[:3], rstats[:3], rtol=1e-13)
+    rn = oracle.normals(pts, 30, 0.01)
+    ridx, rd2, rcnt = oracle.knn(pts, None, 8)
+    seen = np.zeros(len(pts), dtype=int)
+    for r in range(world):
+        res = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(res["kept"], rkept)
+        assert np.array_equal(res["stats"], np.array(stats1))  # same bits as one process
+        assert np.abs(res["nrm"] - rn).max() < 1e-6
+        assert np.array_equal(res["idx"], ridx[res["owned"]]) and np.array_equal(res["d2"], rd2[res["owned"]])
+        assert np.array_equal(res["cnt"], rcnt[res["owned"]])
+        seen[res["owned"]] += 1
+    assert (seen == 1).all()
