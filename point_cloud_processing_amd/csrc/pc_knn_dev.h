@@ -146,6 +146,9 @@ struct ScanArgs {
     // wave-per-query re-run: the index levels, finest first
     Level lv[MAX_LEVELS + MAX_FINER];  // (the finer grids made for crowded queries come first)
     int nlv;
+    // ring of the first block of a listed query that comes without a bound: 2 where a tile pass of the same
+    // (only) level has looked at the query's 3 x 3 x 3 cells already and found them wanting, else 1
+    int first_ring;
 };
 
 // an open query (flag set) that the pass of flag_max answers

@@ -658,6 +658,9 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     A.qlist = A.flag_list;
     A.qub = A.flag_ub;
     A.qcount = A.flag_count;
+    // (an index of one level: whoever is listed without a bound has had its 27 cells searched in vain by the tile
+    // pass -- all but the few queries of over-full tiles, which lose nothing by the wider first block)
+    A.first_ring = nlv == 1 && g->finer == nullptr && !g->uneven ? 2 : 1;
     PC_TRY(pc_launch_wave_query(ctx, g, mode, A, st));
     // ... and whatever that stage could not hold is left for the per-lane scan of the caller
     A.qlist = A.flag2_list;

@@ -22,7 +22,7 @@ constexpr int AHEAD = 4;  // candidate records in flight per lane
 constexpr uint32_t PROBE_MIN = 2048, PROBE_LEN = 512;  // blocks with more candidates are probed first, with so many
 
 template <typename REC, int MODE>
-__global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
+__global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void k_wave_query(ScanArgs A) {
     __shared__ double sv_d[SCAP];
     __shared__ uint32_t sv_pos[SCAP];
     __shared__ int32_t sv_id[SCAP];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(PC_WAVE) void k_wave_query(ScanArgs A) {
         int32_t qid;
         RecTraits<REC>::load((A.qrec ? reinterpret_cast<const REC *>(A.qrec) : rec0) + spos, qx, qy, qz, qid);
         const double qv[3] = {qx, qy, qz};
-        int cnt = 0, lvl = 0, R = 1;
+        int cnt = 0, lvl = 0, R = ub < INFINITY || r2lim >= 0.0 ? 1 : max(A.first_ring, 1);
         bool spilled = false, jumped = false;
         // The finest level and ring whose block holds everything within sqrt(bound2) of the query: the ring
         // reaches R cells beyond the query's own cell on every side, i.e. at least R * cell.
