@@ -217,6 +217,40 @@ int pc_scatter_rows(pc_ctx *ctx, const double *src_dev, const int32_t *idx_dev, 
 int pc_gather_rows_f32(pc_ctx *ctx, const float *src_dev, const int32_t *idx_dev, int64_t m, float *dst_dev,
                        void *stream);
 
+/* ---- slabs: one rank of a multi-GPU job indexes only its part of the cloud --------------------------------
+ * The reference has no distribution of any kind; these four calls serve the query sharding of
+ * remove_statistical_outlier / estimate_normals (filtering_adapter.py:91, pointcloud_preprocess.py:109-114)
+ * where sorting all n points on every rank would bound the speed-up.  A rank takes the points whose coordinate
+ * along `axis` lies in [own_lo - halo, own_hi + halo) (pc_select_slab + pc_gather_rows*), indexes that subset
+ * (pc_grid_build), searches the sorted positions of its own interval (pc_grid_axis_range + pc_knn_fused_compact)
+ * and lets pc_slab_finish translate the rows back to indices of the whole cloud and count the answers that the
+ * subset cannot vouch for (k-th distance beyond the nearer open face of the slab): those are repeated on a
+ * wider slab or a full index, so results stay exact. */
+/* Counts of the n points per bin of [lo, hi] along axis (nbins <= 4096 equal bins, ends clamped), into host
+ * memory: what the cuts between the ranks' intervals are chosen from.  Synchronises the stream. */
+int pc_axis_histogram(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi, int nbins,
+                      uint32_t *out_counts, void *stream);
+/* Ascending indices of the points with lo <= coordinate < hi along axis (+-inf allowed); out_index_dev holds up to n
+ * entries, *m receives their number.  Synchronises the stream. */
+int pc_select_slab(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi,
+                   int32_t *out_index_dev, int64_t *m, void *stream);
+/* The range of sorted positions made of the whole z layers of cells that hold every point with lo <= z <= hi (z is
+ * the slowest digit of the cell keys: a z interval is one range).  Synchronises the stream. */
+int pc_grid_axis_range(pc_ctx *ctx, const pc_grid *grid, double lo, double hi, int64_t *s_begin, int64_t *s_end,
+                       void *stream);
+/* After pc_knn_fused_compact over a slab subset (sub_xyz: the subset's rows, sub_index: their indices in the whole
+ * cloud; m_rows result rows): rows whose query has own_lo <= z < own_hi get owned = index in the whole cloud and
+ * neighbour indices translated likewise, all others owned = -1 (rows to ignore).  open_lo / open_hi: the subset's
+ * z faces beyond which the cloud has more points (-inf / +inf where it has none).  avg_full (may be NULL, else n
+ * doubles): avg_rows of the own rows written at their index in the whole cloud.  *n_own: own rows; *n_uncertain:
+ * own rows whose k-th squared distance is not below the squared distance to the nearer open face (or that found
+ * fewer than k although points may hide beyond a face within the radius).  cnt_dev may be NULL (every row has k).
+ * Synchronises the stream. */
+int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, const int32_t *sub_index_dev, int64_t m_rows, int k,
+                   double radius, int32_t *idx_dev, const void *d2_dev, int d2_dtype, const int32_t *cnt_dev,
+                   int32_t *owned_dev, double own_lo, double own_hi, double open_lo, double open_hi,
+                   const double *avg_rows_dev, double *avg_full_dev, int64_t *n_own, int64_t *n_uncertain, void *stream);
+
 /* PointCloud.orient_normals_consistent_tangent_plane(k) (app/Core/pointcloud_preprocess.py:115): turns the
  * n normals (n x 3 fp64, in place) so that they agree along the minimum spanning tree of the neighbour graph
  * given by knn_idx (n x k rows of pc_knn over the same cloud; knn_cnt = valid entries per row, or NULL: all),

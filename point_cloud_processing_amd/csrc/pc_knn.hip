@@ -529,6 +529,7 @@ int64_t pc_sor_chunks(int64_t n) { return n > 0 ? (n + PC_SOR_CHUNK - 1) / PC_SO
 int pc_sor_chunk_sums(pc_ctx *ctx, const pc_grid *grid, const double *avg_dev, int compact, int64_t s_begin, int64_t s_end,
                       int what, double mean, double *partials_dev, void *stream) {
     PcLock lock(ctx, stream);
+    if (ctx && grid && range_ok(grid, s_begin, s_end) && s_end == s_begin) return PC_OK;  // (a rank without a chunk of its own)
     if (!ctx || !grid || !range_ok(grid, s_begin, s_end) || (s_end > s_begin && (!avg_dev || !partials_dev)) ||
         s_begin % PC_SOR_CHUNK != 0 || (s_end % PC_SOR_CHUNK != 0 && s_end != grid->n) || (what != 0 && what != 1))
         return pc_fail(ctx, PC_BAD_ARG, "pc_sor_chunk_sums: the range must consist of whole chunks");

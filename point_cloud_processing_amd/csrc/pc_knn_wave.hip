@@ -22,7 +22,7 @@ constexpr int AHEAD = 4;  // candidate records in flight per lane
 constexpr uint32_t PROBE_MIN = 2048, PROBE_LEN = 512;  // blocks with more candidates are probed first, with so many
 
 template <typename REC, int MODE>
-__global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void k_wave_query(ScanArgs A) {
+__global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(MODE == M_ALL ? 3 : 4))) void k_wave_query(ScanArgs A) {
     __shared__ double sv_d[SCAP];
     __shared__ uint32_t sv_pos[SCAP];
     __shared__ int32_t sv_id[SCAP];

@@ -1,0 +1,216 @@
+// Slabs: one rank of a multi-GPU job indexes only ITS part of the cloud.
+//
+// With a replicated index every rank sorts all n points, which bounds the speed-up of a job whose search is
+// already sharded.  A slab is the set of points whose z lies in [own_lo - halo, own_hi + halo): the rank
+// indexes that subset alone (pc_grid_build on the gathered rows), answers the queries with z in
+// [own_lo, own_hi) and checks every answer against the two open faces of the slab: a result whose k-th
+// distance is below the distance to the nearest open face cannot have missed a point outside the subset
+// (such a point lies beyond the face).  Results are exact, not approximate: the caller repeats the queries
+// that fail the check on a wider slab or on a full index.  z is the slowest digit of the cell keys, so the
+// queries of a z interval are one range of sorted positions (pc_grid_axis_range) for the *_compact searches.
+// Subset rows keep the cloud's order, so "lower index first" between equal distances picks the same point.
+#include <algorithm>
+
+#include "pc_knn_dev.h"
+
+namespace {
+
+constexpr int HIST_MAX_BINS = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_axis_hist(const T *__restrict__ xyz, int64_t n, int axis, double lo,
+                                                   double inv_width, int nbins, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[HIST_MAX_BINS];
+    for (int b = threadIdx.x; b < nbins; b += 256) h[b] = 0u;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double t = floor(((double)xyz[3 * i + axis] - lo) * inv_width);
+        const int b = !(t > 0.0) ? 0 : (t >= (double)nbins ? nbins - 1 : (int)t);
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_slab_flags(const T *__restrict__ xyz, int64_t n, int axis, double lo, double hi,
+                                                    uint8_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = (double)xyz[3 * i + axis];
+    flags[i] = (v >= lo && v < hi) ? 1 : 0;
+}
+
+// first sorted positions of z layers la and lb + 1, where la / lb are the layers of lo / hi
+__global__ void k_axis_range(CellIndex ci, GridParams gp, double lo, double hi, int64_t *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto layer = [&](double z) {
+        const double t = floor((z - gp.o[2]) * gp.s);  // (the expression behind the cell keys)
+        return !(t > 0.0) ? 0 : (t >= (double)gp.dim[2] ? gp.dim[2] - 1 : (int)t);
+    };
+    const int la = layer(lo), lb = layer(hi);
+    const int64_t per_layer = (int64_t)gp.dim[1] * gp.dim[0];
+    out[0] = (int64_t)cell_begin(ci, (int64_t)la * per_layer);
+    out[1] = lb + 1 >= gp.dim[2] ? (int64_t)ci.n : (int64_t)cell_begin(ci, (int64_t)(lb + 1) * per_layer);
+}
+
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_xyz, const int32_t *__restrict__ gidx,
+                                                     int64_t m_rows, int k, double radius2, int32_t *__restrict__ idx,
+                                                     const TD *__restrict__ d2, const int32_t *__restrict__ cnt,
+                                                     int32_t *__restrict__ owned, double own_lo, double own_hi,
+                                                     double open_lo, double open_hi, const double *__restrict__ avg_rows,
+                                                     double *__restrict__ avg_full, unsigned long long *__restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool own = false, uncertain = false;
+    if (r < m_rows) {
+        const int32_t local = owned[r];
+        const double z = (double)sub_xyz[3 * (size_t)local + 2];
+        own = z >= own_lo && z < own_hi;
+        if (!own) {
+            owned[r] = -1;
+        } else {
+            const int32_t g = gidx[local];
+            owned[r] = g;
+            const int c = cnt ? cnt[r] : k;
+            // no point outside the subset is closer than the nearer open face
+            const double margin = fmin(z - open_lo, open_hi - z);  // (+inf where both faces are the cloud's own ends)
+            const double lim = margin < INFINITY ? margin * margin * (1.0 - 1e-9) : INFINITY;
+            if (c >= k) {
+                // (fp32 rows carry the fp64 distance rounded to nearest: widened by what that can hide)
+                const double dk = (double)d2[(size_t)r * k + (k - 1)] * (sizeof(TD) == 4 ? 1.0 + 1e-6 : 1.0);
+                uncertain = !(dk <= lim);
+            } else {
+                // fewer than k found: final only if nothing can hide beyond the faces within the search radius
+                uncertain = !(lim == INFINITY || (radius2 >= 0.0 && radius2 <= lim));
+            }
+            if (idx)
+                for (int s = 0; s < k; s++) {
+                    const int32_t j = idx[(size_t)r * k + s];
+                    if (j >= 0) idx[(size_t)r * k + s] = gidx[j];
+                }
+            if (avg_full && avg_rows) avg_full[g] = avg_rows[r];
+        }
+    }
+    const unsigned long long mo = __ballot(own), mu = __ballot(uncertain);
+    if ((threadIdx.x & (PC_WAVE - 1)) == 0) {
+        if (mo) atomicAdd(&counts[0], (unsigned long long)__popcll(mo));
+        if (mu) atomicAdd(&counts[1], (unsigned long long)__popcll(mu));
+    }
+}
+
+}  // namespace
+
+extern "C" int pc_axis_histogram(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi,
+                                 int nbins, uint32_t *out_counts, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || n < 0 || (n > 0 && !xyz_dev) || axis < 0 || axis > 2 || nbins < 1 || nbins > HIST_MAX_BINS || !out_counts ||
+        !(hi >= lo) || (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_axis_histogram");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (int b = 0; b < nbins; b++) out_counts[b] = 0u;
+    if (n == 0) return PC_OK;
+    Scratch h(ctx, sizeof(uint32_t) * (size_t)nbins);
+    if (!h.ok()) return pc_fail(ctx, PC_NOMEM, "histogram");
+    PC_HIP(hipMemsetAsync(h.p, 0, sizeof(uint32_t) * (size_t)nbins, st));
+    const double inv_width = hi > lo ? (double)nbins / (hi - lo) : 0.0;
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_axis_hist<float>, dim3(nb), dim3(256), 0, st, (const float *)xyz_dev, n, axis, lo, inv_width,
+                           nbins, h.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_axis_hist<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz_dev, n, axis, lo, inv_width,
+                           nbins, h.as<uint32_t>());
+    PC_HIP(hipGetLastError());
+    PC_HIP(hipMemcpyAsync(out_counts, h.p, sizeof(uint32_t) * (size_t)nbins, hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    return PC_OK;
+}
+
+extern "C" int pc_select_slab(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi,
+                              int32_t *out_index_dev, int64_t *m, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || n < 0 || n > INT32_MAX || (n > 0 && (!xyz_dev || !out_index_dev)) || axis < 0 || axis > 2 || !m ||
+        (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_select_slab");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *m = 0;
+    if (n == 0) return PC_OK;
+    Scratch flags(ctx, (size_t)n);
+    if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "slab flags");
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_slab_flags<float>, dim3(nb), dim3(256), 0, st, (const float *)xyz_dev, n, axis, lo, hi,
+                           flags.as<uint8_t>());
+    else
+        hipLaunchKernelGGL(k_slab_flags<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz_dev, n, axis, lo, hi,
+                           flags.as<uint8_t>());
+    PC_HIP(hipGetLastError());
+    return pc_compact_flags(ctx, flags.as<uint8_t>(), n, out_index_dev, m, st);  // (ascending: the cloud's order is kept)
+}
+
+extern "C" int pc_grid_axis_range(pc_ctx *ctx, const pc_grid *grid, double lo, double hi, int64_t *s_begin, int64_t *s_end,
+                                  void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || !grid || !s_begin || !s_end || !(hi >= lo)) return pc_fail(ctx, PC_BAD_ARG, "pc_grid_axis_range");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *s_begin = *s_end = 0;
+    if (grid->n == 0) return PC_OK;
+    Scratch out(ctx, 2 * sizeof(int64_t));
+    if (!out.ok()) return pc_fail(ctx, PC_NOMEM, "range scratch");
+    hipLaunchKernelGGL(k_axis_range, dim3(1), dim3(64), 0, st, grid->index(), grid->gp, lo, hi, out.as<int64_t>());
+    PC_HIP(hipGetLastError());
+    int64_t *hp = reinterpret_cast<int64_t *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(hp, out.p, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    *s_begin = hp[0];
+    *s_end = hp[1];
+    return PC_OK;
+}
+
+extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, const int32_t *sub_index_dev, int64_t m_rows,
+                              int k, double radius, int32_t *idx_dev, const void *d2_dev, int d2_dtype,
+                              const int32_t *cnt_dev, int32_t *owned_dev, double own_lo, double own_hi, double open_lo,
+                              double open_hi, const double *avg_rows_dev, double *avg_full_dev, int64_t *n_own,
+                              int64_t *n_uncertain, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || m_rows < 0 || k < 1 || k > PC_MAX_K || !n_own || !n_uncertain ||
+        (m_rows > 0 && (!sub_xyz_dev || !sub_index_dev || !d2_dev || !owned_dev)) || (dtype != PC_F32 && dtype != PC_F64) ||
+        (d2_dtype != PC_F32 && d2_dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_slab_finish");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    *n_own = *n_uncertain = 0;
+    if (m_rows == 0) return PC_OK;
+    Scratch counts(ctx, 2 * sizeof(unsigned long long));
+    if (!counts.ok()) return pc_fail(ctx, PC_NOMEM, "slab counts");
+    PC_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned long long), st));
+    const unsigned nb = (unsigned)((m_rows + 255) / 256);
+    const double r2 = radius >= 0 ? radius * radius : -1.0;
+    unsigned long long *c = counts.as<unsigned long long>();
+#define PC_SLAB_FINISH(T, TD)                                                                                             \
+    hipLaunchKernelGGL((k_slab_finish<T, TD>), dim3(nb), dim3(256), 0, st, (const T *)sub_xyz_dev, sub_index_dev, m_rows, k, \
+                       r2, idx_dev, (const TD *)d2_dev, cnt_dev, owned_dev, own_lo, own_hi, open_lo, open_hi, avg_rows_dev, \
+                       avg_full_dev, c)
+    if (dtype == PC_F32 && d2_dtype == PC_F32)
+        PC_SLAB_FINISH(float, float);
+    else if (dtype == PC_F32)
+        PC_SLAB_FINISH(float, double);
+    else if (d2_dtype == PC_F32)
+        PC_SLAB_FINISH(double, float);
+    else
+        PC_SLAB_FINISH(double, double);
+#undef PC_SLAB_FINISH
+    PC_HIP(hipGetLastError());
+    unsigned long long *hp = reinterpret_cast<unsigned long long *>(ctx->pinned);
+    PC_HIP(hipMemcpyAsync(hp, counts.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PC_HIP(hipStreamSynchronize(st));
+    *n_own = (int64_t)hp[0];
+    *n_uncertain = (int64_t)hp[1];
+    return PC_OK;
+}

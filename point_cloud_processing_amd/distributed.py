@@ -133,6 +133,74 @@ def normals_steps(engine, pts, k: int, radius: float, cache: dict, rank: int, wo
     return full
 
 
+# ---- slabs: every rank indexes only its own part of the cloud -----------------------------------------
+SLAB_BINS = 4096   # bins of the z histogram the cuts are chosen from
+SLAB_HALO = 2.0    # halo in units of the neighbour distance of a cloud spread evenly over its bounding box
+
+
+def slab_cuts(engine, pts, cache: dict, k: int, world: int):
+    """Where the ranks' z intervals begin and end: ``(cuts, halo)`` with ``cuts[r] <= z < cuts[r + 1]`` owned by
+    rank r (first and last cut infinite), chosen at bin edges of a z histogram so that the intervals hold about
+    n / world points each, and the halo every rank indexes beyond its interval.  ``None`` where slabs do not
+    pay (a cloud without depth along z, intervals thinner than their halos): the callers then shard the queries
+    of a replicated index.  Every rank computes the same answer from the same cloud."""
+    n = len(pts)
+    if world <= 1:
+        return [-np.inf, np.inf], 0.0
+    mn, mx = engine.bbox(pts, cache)
+    ext = np.asarray(mx, dtype=np.float64) - np.asarray(mn, dtype=np.float64)
+    if n < 2 * world or not ext[2] > 0:
+        return None
+    hist = np.asarray(engine.axis_histogram(pts, cache, 2, float(mn[2]), float(mx[2]), SLAB_BINS), dtype=np.int64)
+    cum = np.cumsum(hist)
+    width = ext[2] / SLAB_BINS
+    cuts = [-np.inf]
+    for r in range(1, world):
+        b = int(np.searchsorted(cum, (r * n) // world))  # first bin whose running count reaches the rank's share
+        cuts.append(float(mn[2] + (b + 1) * width))
+    cuts.append(np.inf)
+    floor_ext = np.maximum(ext, 1e-3 * ext.max())
+    halo = SLAB_HALO * float((k * np.prod(floor_ext) / n) ** (1.0 / 3.0))
+    inner = np.diff(np.array([mn[2]] + cuts[1:-1] + [mx[2]]))
+    if not (np.diff(cuts[1:-1]) > 0).all() or inner.min() < 2.0 * halo:
+        return None
+    return cuts, halo
+
+
+def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, **search_kw):
+    """``pipeline_steps`` with an index of the rank's own slab instead of a replicated one: rows, mean distances
+    and normals of the rank's z interval from ONE search of the slab, then one exchange -- the mean distances
+    put together (each rank fills its own rows of a zeroed array: adding the others' zeros is exact), with the
+    number of answers the slabs cannot vouch for riding along.  If there are any, the whole job is repeated on
+    the replicated index: results are exact either way.  Returns what ``pipeline_steps`` returns; rows with
+    ``owned`` < 0 belong to a neighbouring rank."""
+    plan = slab_cuts(engine, pts, cache, k, world)
+    if plan is None:
+        return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, **search_kw))
+    cuts, halo = plan
+    n = len(pts)
+    box = engine.zeros_f64(n + 1)
+    sh = engine.slab_search(pts, cache, k, -1.0, cuts[rank], cuts[rank + 1], halo, want_avg=True, want_normals=True,
+                            avg_full=box, **search_kw)
+    box[n] = float(sh["n_uncertain"])
+    box = yield box
+    if float(box[n]) != 0.0:
+        return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, **search_kw))
+    kept, stats = engine.sor_from_avg(box, n, std_ratio)
+    return sh, kept, stats
+
+
+def knn_slab(engine, pts, k: int, cache: dict, rank: int, world: int, **search_kw):
+    """kNN rows of the rank's z interval from an index of its own slab, or ``None`` where slabs do not pay or
+    this rank's slab cannot vouch for all its answers (the caller then uses ``knn_sharded``)."""
+    plan = slab_cuts(engine, pts, cache, k, world)
+    if plan is None:
+        return None
+    cuts, halo = plan
+    sh = engine.slab_search(pts, cache, k, -1.0, cuts[rank], cuts[rank + 1], halo, **search_kw)
+    return sh if sh["n_uncertain"] == 0 else None
+
+
 def sor_sharded(engine, pts, k: int, std_ratio: float, cache: Optional[dict] = None, group=None):
     """Statistical outlier removal with the queries sharded over the ranks of ``group``.
 

@@ -396,6 +396,89 @@ class HipEngine:
                                                   _ptr(out["owned"]), self.stream()), "pc_knn_fused_compact")
         return out
 
+    # -- one rank of a multi-GPU job with an index of its own slab of the cloud -------------------------------
+    def axis_histogram(self, pts, cache, axis: int, lo: float, hi: float, nbins: int) -> np.ndarray:
+        t = self.dev_points(pts, cache)
+        out = np.zeros(nbins, dtype=np.uint32)
+        self._check(self.lib.pc_axis_histogram(self.ctx, _ptr(t), self._dt(t), len(pts), int(axis), float(lo), float(hi),
+                                               int(nbins), out.ctypes.data_as(C.c_void_p), self.stream()),
+                    "pc_axis_histogram")
+        return out
+
+    def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False,
+                    d2_dtype=torch.float64, avg_full=None):
+        """The rank's queries (own_lo <= z < own_hi) answered from an index of the points with z in
+        [own_lo - halo, own_hi + halo) only.  Rows as in ``shard_search`` (always with idx / d2 / cnt), indices
+        those of the whole cloud; rows with ``owned`` < 0 belong to a neighbouring rank and are to be ignored.
+        ``n_uncertain``: own answers the slab cannot vouch for (see pc_slab_finish).  ``avg_full`` (n doubles or
+        more): receives the own rows' mean distances at their index in the whole cloud."""
+        t = self.dev_points(pts, cache)
+        n = len(pts)
+        mn, mx = self.bbox(pts, cache)
+        lo, hi = own_lo - halo, own_hi + halo
+        key = ("slab", float(lo), float(hi), 1 if k <= 4 else (2 if k <= 16 else 3))
+        sub = cache.get(key)
+        if sub is None:
+            gidx = self.empty((max(n, 1),), torch.int32)
+            m = C.c_int64(0)
+            self._check(self.lib.pc_select_slab(self.ctx, _ptr(t), self._dt(t), n, 2, float(lo), float(hi), _ptr(gidx),
+                                                C.byref(m), self.stream()), "pc_select_slab")
+            m = m.value
+            gidx = gidx[:m].clone()  # (the n-entry buffer goes back)
+            xyz = self.empty((max(m, 1), 3), t.dtype)[:m]
+            gather = self.lib.pc_gather_rows_f32 if t.dtype == torch.float32 else self.lib.pc_gather_rows
+            self._check(gather(self.ctx, _ptr(t), _ptr(gidx), m, _ptr(xyz), self.stream()), "pc_gather_rows")
+            sub = (gidx, xyz, DeviceGrid(self, xyz, m, k) if m > 0 else None)
+            cache[key] = sub
+        gidx, xyz, g = sub
+        m = gidx.numel()
+        b, e = C.c_int64(0), C.c_int64(0)
+        if g is not None:
+            self._check(self.lib.pc_grid_axis_range(self.ctx, g.h, float(own_lo), float(own_hi), C.byref(b), C.byref(e),
+                                                    self.stream()), "pc_grid_axis_range")
+        b, e = b.value, e.value
+        rows = e - b
+        out = {"owned": self.empty((max(rows, 1),), torch.int32)[:rows], "idx": self.empty((rows, k), torch.int32),
+               "d2": self.empty((rows, k), d2_dtype), "cnt": self.empty((rows,), torch.int32), "sub_n": m}
+        if want_avg or avg_full is not None:
+            out["avg"] = self.empty((rows,), torch.float64)
+        if want_normals:
+            out["normals"] = self.empty((rows, 3), torch.float64)
+        n_own, n_unc = C.c_int64(0), C.c_int64(0)
+        if rows > 0:
+            self._check(self.lib.pc_knn_fused_compact(self.ctx, g.h, b, e, int(k), float(radius), _ptr(out["idx"]),
+                                                      _ptr(out["d2"]), self._dt(out["d2"]), _ptr(out["cnt"]),
+                                                      _ptr(out.get("avg")), _ptr(out.get("normals")), _ptr(out["owned"]),
+                                                      self.stream()), "pc_knn_fused_compact")
+            # faces of the subset beyond which the cloud goes on
+            open_lo = float(lo) if lo > mn[2] else -np.inf
+            open_hi = float(hi) if hi <= mx[2] else np.inf
+            self._check(self.lib.pc_slab_finish(self.ctx, _ptr(xyz), self._dt(xyz), _ptr(gidx), rows, int(k), float(radius),
+                                                _ptr(out["idx"]), _ptr(out["d2"]), self._dt(out["d2"]), _ptr(out["cnt"]),
+                                                _ptr(out["owned"]), float(own_lo), float(own_hi), open_lo, open_hi,
+                                                _ptr(out.get("avg")), _ptr(avg_full), C.byref(n_own), C.byref(n_unc),
+                                                self.stream()), "pc_slab_finish")
+        out["n_own"], out["n_uncertain"] = n_own.value, n_unc.value
+        return out
+
+    def zeros_f64(self, m: int) -> torch.Tensor:
+        return torch.zeros((m,), dtype=torch.float64, device=self.device)
+
+    def sor_from_avg(self, avg: torch.Tensor, n: int, std_ratio: float):
+        """Kept indices and (mean, std, threshold, valid) from the n mean distances as they lie (a fixed tree over
+        the array: the same bits on every rank)."""
+        from .geometry import LazyIndices
+
+        avg = avg[:n]
+        mean, std, thr, valid = self.sor_stats(avg, std_ratio)
+        if valid == 0:
+            return self.no_indices(), (0.0, 0.0, 0.0, 0)
+        kept = self.empty((max(n, 1),), torch.int32)
+        nk = C.c_int64(0)
+        self._check(self.lib.pc_sor_select(self.ctx, _ptr(avg), n, float(thr), None, _ptr(kept), C.byref(nk),
+                                           self.stream()), "pc_sor_select")
+        return LazyIndices(self, kept[: nk.value], nk.value), (mean, std, thr, valid)
+
     def chunk_sums(self, pts, cache, k, avg, b, e, what, mean, compact=True) -> torch.Tensor:
         """Zeroed partial-sum array of the whole cloud with the chunks of [b, e) filled in."""
         g = self.grid(pts, cache, k)

@@ -148,3 +148,99 @@ def test_hip_engine_in_real_processes(hip, oracle, tmp_path, world):
         assert np.array_equal(res["cnt"], rcnt[res["owned"]])
         seen[res["owned"]] += 1
     assert (seen == 1).all()
+
+
+# ---- slabs: every rank indexes only its own part of the cloud ------------------------------------
+def _slab_clouds():
+    uni = D.uniform_cube(60000, 5)
+    # a cloud that the slabs cannot vouch for: two dense layers and a few stray points in the void between
+    # them, whose neighbours lie farther away than any halo sized for the cloud's mean density
+    rng = np.random.default_rng(6)
+    lay = rng.random((12000, 3))
+    lay[:, 2] = lay[:, 2] * 0.1 + np.where(np.arange(12000) % 2 == 0, 0.0, 0.9)
+    mid = rng.random((40, 3))
+    mid[:, 2] = 0.1 + 0.8 * mid[:, 2]
+    stray = np.concatenate([lay, mid]).astype(np.float32).astype(np.float64)
+    return {"uniform": uni, "stray": stray, "flat": D.lidar_frame(4)[:20000]}
+
+
+def _check_slab_results(pts, res, k, oracle, want_slab):
+    """Every rank's rows against the whole-cloud oracle; the ranks' own rows partition the cloud."""
+    from point_cloud_processing_amd import distributed as PD
+
+    host = lambda a: a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+    ridx, rd2, rcnt = oracle.knn(pts, None, k)
+    ravg, rn = oracle.sor_avg(pts, k), oracle.normals(pts, k)
+    rkept, _, rstats = oracle.sor(pts, k, 2.0)
+    seen = np.zeros(len(pts), dtype=int)
+    first = None
+    for sh, kept, stats in res:
+        assert ("sub_n" in sh) == want_slab
+        owned = host(sh["owned"])
+        own = owned >= 0
+        o = owned[own]
+        assert np.array_equal(host(sh["idx"])[own], ridx[o]) and np.array_equal(host(sh["d2"])[own], rd2[o])
+        assert np.array_equal(host(sh["cnt"])[own], rcnt[o])
+        np.testing.assert_allclose(host(sh["avg"])[own], ravg[o], rtol=1e-13)
+        assert len(o) == 0 or np.abs(host(sh["normals"])[own] - rn[o]).max() < 1e-6
+        assert np.array_equal(host(kept), rkept)
+        np.testing.assert_allclose(stats[:3], rstats[:3], rtol=1e-12)
+        first = first or stats
+        assert stats == first  # the same bits on every rank
+        seen[o] += 1
+    assert (seen == 1).all()
+    return first
+
+
+@pytest.mark.parametrize("name", ["uniform", "stray", "flat"])
+def test_slab_pipeline_matches_whole_cloud(oracle, name):
+    """pipeline_steps_slab with the oracle engine for several pretended worlds: exact rows whether the slabs
+    vouch for every answer ("uniform"), fall back because of one stray point ("stray") or do not pay at all
+    ("flat": a cloud without depth along z)."""
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd import distributed as PD
+
+    pts = _slab_clouds()[name]
+    k = 8
+    stats = []
+    for world in (1, 2, 4):
+        res = PD.run_emulated(lambda r: PD.pipeline_steps_slab(OracleEngine(), pts, k, 2.0, {}, r, world), world)
+        stats.append(_check_slab_results(pts, res, k, oracle, want_slab=name == "uniform" or world == 1))
+    if name == "uniform":
+        assert stats[0] == stats[1] == stats[2]  # one fixed tree over the whole array: any world, same bits
+
+
+def test_slab_cuts_partition_and_balance(oracle):
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd import distributed as PD
+
+    pts = _slab_clouds()["uniform"]
+    cuts, halo = PD.slab_cuts(OracleEngine(), pts, {}, 8, 4)
+    assert cuts[0] == -np.inf and cuts[-1] == np.inf and (np.diff(cuts[1:-1]) > 0).all() and halo > 0
+    counts = [int(((pts[:, 2] >= cuts[r]) & (pts[:, 2] < cuts[r + 1])).sum()) for r in range(4)]
+    assert sum(counts) == len(pts) and max(counts) < 1.1 * len(pts) / 4
+    assert PD.slab_cuts(OracleEngine(), pts, {}, 16, 8) is None  # intervals thinner than their halos
+    assert PD.slab_cuts(OracleEngine(), _slab_clouds()["flat"], {}, 16, 8) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["uniform", "stray", "planes"])
+def test_slab_pipeline_on_the_hip_engine(hip, oracle, name):
+    """The same with the HIP engine (slab subsets, their own indexes, pc_slab_finish) for 1, 2, 3 and 8
+    pretended ranks on this GPU."""
+    from point_cloud_processing_amd import distributed as PD
+
+    pts = {"planes": lambda: D.planar_patches(300000, 7, extent=20.0, n_patches=12),
+           "uniform": lambda: D.uniform_cube(400000, 5), "stray": lambda: _slab_clouds()["stray"]}[name]()
+    k = 8 if name == "uniform" else 12
+    stats = []
+    for world in (1, 2, 3, 8):
+        cache = {}
+        res = PD.run_emulated(lambda r: PD.pipeline_steps_slab(hip, pts, k, 2.0, cache, r, world), world)
+        plan = PD.slab_cuts(hip, pts, {}, k, world)
+        slabbed = "sub_n" in res[0][0]
+        assert slabbed == (plan is not None and (name != "stray" or world == 1))
+        stats.append(_check_slab_results(pts, res, k, oracle, want_slab=slabbed))
+    if name == "uniform":
+        assert PD.slab_cuts(hip, pts, {}, k, 8) is not None
+        assert all(s == stats[0] for s in stats)
