@@ -125,7 +125,8 @@ struct ScanArgs {
     int ntile[3];           // tiles per axis
     int64_t s_end;          // self-query range end (sorted position)
     int cand_cap;           // candidates the LDS block holds
-    const uint32_t *tile_list;  // occupied tiles (sparse index), or NULL: blockIdx is the tile id
+    const uint32_t *tile_list;  // occupied tiles (sparse index), or NULL: blockIdx + tile_base is the tile id
+    int64_t tile_base;          // first tile of the launch (query shards launch the tiles of their own z layers only)
     // multi-level passes: per-point flags and bounds, indexed by ORIGINAL point index
     const uint8_t *qflag_in;    // NULL: every point of the range is a query; else only flagged points
     uint8_t *qflag_out;         // where uncertified queries are flagged for the next (coarser) pass;

@@ -543,6 +543,32 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             // (no open query starts at or before this level)
         } else {
             if (nt <= 0) continue;
+            A.tile_base = 0;
+            if (i == 0 && !A.qrec && !A.tile_list && (A.s_begin > 0 || A.s_end < l->n) && A.s_end > A.s_begin) {
+                // A query shard: its sorted positions are whole z layers of cells (more or less), i.e. one run of
+                // tile ids -- only those are launched.  (Launching all tiles and letting the others leave at once
+                // costs more than their launch: consecutive tiles share an XCD, so a shard's tiles would all sit on
+                // one or two of the eight XCDs while the rest of the GPU watches.  10 M points, one slice of eight:
+                // 1.62 ms against 1.77 ms for the whole cloud.)
+                const size_t rsz = g->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64), zoff = g->dtype == PC_F32 ? 8 : 16;
+                char *hp = reinterpret_cast<char *>(ctx->pinned);
+                const char *rb = reinterpret_cast<const char *>(l->rec);
+                PC_HIP(hipMemcpyAsync(hp, rb + rsz * (size_t)A.s_begin + zoff, 8, hipMemcpyDeviceToHost, st));
+                PC_HIP(hipMemcpyAsync(hp + 8, rb + rsz * (size_t)(A.s_end - 1) + zoff, 8, hipMemcpyDeviceToHost, st));
+                PC_HIP(hipStreamSynchronize(st));
+                int tz[2];
+                for (int e = 0; e < 2; e++) {
+                    const double z = g->dtype == PC_F32 ? (double)*reinterpret_cast<const float *>(hp + 8 * e)
+                                                        : *reinterpret_cast<const double *>(hp + 8 * e);
+                    const double t = floor((z - l->gp.o[2]) * l->gp.s);  // (the expression behind the cell keys)
+                    const int c = !(t > 0.0) ? 0 : (t >= (double)l->gp.dim[2] ? l->gp.dim[2] - 1 : (int)t);
+                    tz[e] = c / l->tile[2];
+                }
+                if (tz[1] >= tz[0]) {
+                    A.tile_base = (int64_t)tz[0] * A.ntile[0] * A.ntile[1];
+                    nt = (int64_t)(tz[1] - tz[0] + 1) * A.ntile[0] * A.ntile[1];
+                }
+            }
             const int nw = l->uneven ? uneven_waves(ctx, nt) : std::max(1, l->tile_waves);
             if (knobs.debug)
                 fprintf(stderr, "[pc_amd]   tile pass %d: tile %dx%dx%d cap %d waves %d tiles %lld\n", i, l->tile[0], l->tile[1],

@@ -839,7 +839,7 @@ void k_tile_scan(ScanArgs A) {
         const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = bid & 7u;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid;
+    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid + A.tile_base;
     const int tx = (int)(t % A.ntile[0]);
     t /= A.ntile[0];
     const int ty = (int)(t % A.ntile[1]);

@@ -56,9 +56,19 @@ __global__ void k_axis_range(CellIndex ci, GridParams gp, double lo, double hi, 
     out[1] = lb + 1 >= gp.dim[2] ? (int64_t)ci.n : (int64_t)cell_begin(ci, (int64_t)(lb + 1) * per_layer);
 }
 
+// neighbour indices of the subset -> indices of the whole cloud, element by element (coalesced; the rows of
+// queries outside the rank's interval are translated too, which harms nothing)
+__global__ __launch_bounds__(256) void k_slab_translate(int32_t *__restrict__ idx, int64_t count,
+                                                        const int32_t *__restrict__ gidx) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    const int32_t j = idx[e];
+    if (j >= 0) idx[e] = gidx[j];
+}
+
 template <typename T, typename TD>
 __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_xyz, const int32_t *__restrict__ gidx,
-                                                     int64_t m_rows, int k, double radius2, int32_t *__restrict__ idx,
+                                                     int64_t m_rows, int k, double radius2,
                                                      const TD *__restrict__ d2, const int32_t *__restrict__ cnt,
                                                      int32_t *__restrict__ owned, double own_lo, double own_hi,
                                                      double open_lo, double open_hi, const double *__restrict__ avg_rows,
@@ -86,11 +96,6 @@ __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_x
                 // fewer than k found: final only if nothing can hide beyond the faces within the search radius
                 uncertain = !(lim == INFINITY || (radius2 >= 0.0 && radius2 <= lim));
             }
-            if (idx)
-                for (int s = 0; s < k; s++) {
-                    const int32_t j = idx[(size_t)r * k + s];
-                    if (j >= 0) idx[(size_t)r * k + s] = gidx[j];
-                }
             if (avg_full && avg_rows) avg_full[g] = avg_rows[r];
         }
     }
@@ -193,9 +198,12 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
     const unsigned nb = (unsigned)((m_rows + 255) / 256);
     const double r2 = radius >= 0 ? radius * radius : -1.0;
     unsigned long long *c = counts.as<unsigned long long>();
+    if (idx_dev)
+        hipLaunchKernelGGL(k_slab_translate, dim3((unsigned)((m_rows * k + 255) / 256)), dim3(256), 0, st, idx_dev, m_rows * k,
+                           sub_index_dev);
 #define PC_SLAB_FINISH(T, TD)                                                                                             \
     hipLaunchKernelGGL((k_slab_finish<T, TD>), dim3(nb), dim3(256), 0, st, (const T *)sub_xyz_dev, sub_index_dev, m_rows, k, \
-                       r2, idx_dev, (const TD *)d2_dev, cnt_dev, owned_dev, own_lo, own_hi, open_lo, open_hi, avg_rows_dev, \
+                       r2, (const TD *)d2_dev, cnt_dev, owned_dev, own_lo, own_hi, open_lo, open_hi, avg_rows_dev, \
                        avg_full_dev, c)
     if (dtype == PC_F32 && d2_dtype == PC_F32)
         PC_SLAB_FINISH(float, float);

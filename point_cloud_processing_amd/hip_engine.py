@@ -406,12 +406,24 @@ class HipEngine:
         return out
 
     def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False,
-                    d2_dtype=torch.float64, avg_full=None):
+                    d2_dtype=torch.float64, avg_full=None, stage_ms: Optional[dict] = None):
         """The rank's queries (own_lo <= z < own_hi) answered from an index of the points with z in
         [own_lo - halo, own_hi + halo) only.  Rows as in ``shard_search`` (always with idx / d2 / cnt), indices
         those of the whole cloud; rows with ``owned`` < 0 belong to a neighbouring rank and are to be ignored.
         ``n_uncertain``: own answers the slab cannot vouch for (see pc_slab_finish).  ``avg_full`` (n doubles or
-        more): receives the own rows' mean distances at their index in the whole cloud."""
+        more): receives the own rows' mean distances at their index in the whole cloud.  ``stage_ms``: a dict
+        that receives the time of each stage (synchronises after every stage: measurements only)."""
+        import time
+
+        clock = [time.perf_counter()]
+
+        def lap(name):
+            if stage_ms is not None:
+                torch.cuda.synchronize(self.device)
+                now = time.perf_counter()
+                stage_ms[name] = stage_ms.get(name, 0.0) + (now - clock[0]) * 1e3
+                clock[0] = now
+
         t = self.dev_points(pts, cache)
         n = len(pts)
         mn, mx = self.bbox(pts, cache)
@@ -424,12 +436,15 @@ class HipEngine:
             self._check(self.lib.pc_select_slab(self.ctx, _ptr(t), self._dt(t), n, 2, float(lo), float(hi), _ptr(gidx),
                                                 C.byref(m), self.stream()), "pc_select_slab")
             m = m.value
+            lap("select")
             gidx = gidx[:m].clone()  # (the n-entry buffer goes back)
             xyz = self.empty((max(m, 1), 3), t.dtype)[:m]
             gather = self.lib.pc_gather_rows_f32 if t.dtype == torch.float32 else self.lib.pc_gather_rows
             self._check(gather(self.ctx, _ptr(t), _ptr(gidx), m, _ptr(xyz), self.stream()), "pc_gather_rows")
+            lap("gather")
             sub = (gidx, xyz, DeviceGrid(self, xyz, m, k) if m > 0 else None)
             cache[key] = sub
+            lap("index")
         gidx, xyz, g = sub
         m = gidx.numel()
         b, e = C.c_int64(0), C.c_int64(0)
@@ -445,11 +460,13 @@ class HipEngine:
         if want_normals:
             out["normals"] = self.empty((rows, 3), torch.float64)
         n_own, n_unc = C.c_int64(0), C.c_int64(0)
+        lap("range+outputs")
         if rows > 0:
             self._check(self.lib.pc_knn_fused_compact(self.ctx, g.h, b, e, int(k), float(radius), _ptr(out["idx"]),
                                                       _ptr(out["d2"]), self._dt(out["d2"]), _ptr(out["cnt"]),
                                                       _ptr(out.get("avg")), _ptr(out.get("normals")), _ptr(out["owned"]),
                                                       self.stream()), "pc_knn_fused_compact")
+            lap("search")
             # faces of the subset beyond which the cloud goes on
             open_lo = float(lo) if lo > mn[2] else -np.inf
             open_hi = float(hi) if hi <= mx[2] else np.inf
@@ -458,6 +475,7 @@ class HipEngine:
                                                 _ptr(out["owned"]), float(own_lo), float(own_hi), open_lo, open_hi,
                                                 _ptr(out.get("avg")), _ptr(avg_full), C.byref(n_own), C.byref(n_unc),
                                                 self.stream()), "pc_slab_finish")
+        lap("finish")
         out["n_own"], out["n_uncertain"] = n_own.value, n_unc.value
         return out
 
