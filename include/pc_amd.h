@@ -238,8 +238,15 @@ int pc_select_slab(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int a
  * the slowest digit of the cell keys: a z interval is one range).  Synchronises the stream. */
 int pc_grid_axis_range(pc_ctx *ctx, const pc_grid *grid, double lo, double hi, int64_t *s_begin, int64_t *s_end,
                        void *stream);
+/* Renames the points of an index built over a subset of a cloud: point i of the subset becomes labels[i], its
+ * index in the whole cloud (labels ascending, below index_space = the whole cloud's size).  From then on every
+ * "original index" the searches of this grid report -- neighbour indices, owned rows -- is an index of the whole
+ * cloud, and outputs written "at the original index" need index_space rows.  Once per grid, before its first
+ * search.  labels_dev is read by kernels on `stream` and must stay alive until they have run. */
+int pc_grid_relabel(pc_ctx *ctx, pc_grid *grid, const int32_t *labels_dev, int64_t index_space, void *stream);
 /* After pc_knn_fused_compact over a slab subset (sub_xyz: the subset's rows, sub_index: their indices in the whole
- * cloud; m_rows result rows): rows whose query has own_lo <= z < own_hi get owned = index in the whole cloud and
+ * cloud; m_rows result rows; after pc_grid_relabel: sub_xyz = the whole cloud and sub_index = NULL, the rows carry
+ * indices of the whole cloud already): rows whose query has own_lo <= z < own_hi get owned = index in the whole cloud and
  * neighbour indices translated likewise, all others owned = -1 (rows to ignore).  open_lo / open_hi: the subset's
  * z faces beyond which the cloud has more points (-inf / +inf where it has none).  avg_full (may be NULL, else n
  * doubles): avg_rows of the own rows written at their index in the whole cloud.  *n_own: own rows; *n_uncertain:

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("pc_axis_histogram", _i32, [_vp, _vp, _i32, _i64, _i32, _dbl, _dbl, _i32, _vp, _vp]),
     ("pc_select_slab", _i32, [_vp, _vp, _i32, _i64, _i32, _dbl, _dbl, _vp, _pi64, _vp]),
     ("pc_grid_axis_range", _i32, [_vp, _vp, _dbl, _dbl, _pi64, _pi64, _vp]),
+    ("pc_grid_relabel", _i32, [_vp, _vp, _vp, _i64, _vp]),
     ("pc_slab_finish", _i32, [_vp, _vp, _i32, _vp, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl,
                               _vp, _vp, _pi64, _pi64, _vp]),
     ("pc_orient_normals", _i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),

@@ -197,7 +197,12 @@ struct pc_grid {
     // original index: the tile kernel of evenly filled fp32 grids walks 2.5 cells per row instead of 3
     bool halves = false;
     bool uneven = false;  // part of a multi-level index (set on every level)
+    // Original indices (Rec::idx, perm) are below this; 0: below n.  pc_grid_relabel renames the points of an index
+    // built over a subset of a cloud to their indices in the whole cloud, which are below the whole cloud's size:
+    // arrays indexed by original index (per-point flags and bounds of the level passes, output slots) are sized by it.
+    int64_t index_space = 0;
 };
+inline int64_t pc_index_space(const pc_grid *g) { return g->index_space > 0 ? g->index_space : g->n; }
 
 // pc_grid.hip
 // fills g->occupied / g->seen if they are still on the device (synchronises then)

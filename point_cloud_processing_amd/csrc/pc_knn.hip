@@ -500,7 +500,7 @@ int pc_knn_fused_compact(pc_ctx *ctx, const pc_grid *grid, int64_t s_begin, int6
     // position; the coarser levels of a multi-level index (uneven clouds) sort the points differently and look the row
     // up by original index (map filled for the queries of the range; other entries are never read).
     const bool by_position = grid->coarse == nullptr && !grid->uneven;
-    Scratch slot(ctx, by_position ? 0 : sizeof(int32_t) * (size_t)grid->n);
+    Scratch slot(ctx, by_position ? 0 : sizeof(int32_t) * (size_t)pc_index_space(grid));
     if (!slot.ok()) return pc_fail(ctx, PC_NOMEM, "output rows");
     if (!by_position)
         hipLaunchKernelGGL(k_fill_slots, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, grid->perm, s_begin, s_end,

@@ -371,7 +371,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // [counts (256 B)] [list 1] [upper bounds 1] [list 2] [per-point bounds] [per-point flags]; the
     // block returns to the pool when this function ends, which is safe because everything that
     // touches it is ordered on `st`
-    const size_t npt = A.qrec ? (size_t)A.nq : (size_t)g->n;
+    const size_t npt = A.qrec ? (size_t)A.nq : (size_t)pc_index_space(g);  // per-point arrays are indexed by original index
     Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (nlv > 1 ? 9 * npt + 128 : 0));
     if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run lists");
     A.flag_count = flags.as<uint32_t>();

@@ -66,6 +66,16 @@ __global__ __launch_bounds__(256) void k_slab_translate(int32_t *__restrict__ id
     if (j >= 0) idx[e] = gidx[j];
 }
 
+template <typename REC>
+__global__ __launch_bounds__(256) void k_relabel(REC *__restrict__ rec, int32_t *__restrict__ perm, int64_t n,
+                                                 const int32_t *__restrict__ labels) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t g = labels[perm[i]];
+    perm[i] = g;
+    rec[i].idx = g;
+}
+
 template <typename T, typename TD>
 __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_xyz, const int32_t *__restrict__ gidx,
                                                      int64_t m_rows, int k, double radius2,
@@ -73,37 +83,42 @@ __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_x
                                                      int32_t *__restrict__ owned, double own_lo, double own_hi,
                                                      double open_lo, double open_hi, const double *__restrict__ avg_rows,
                                                      double *__restrict__ avg_full, unsigned long long *__restrict__ counts) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool own = false, uncertain = false;
-    if (r < m_rows) {
-        const int32_t local = owned[r];
+    // (grid-stride rows, counts summed per thread, then per block: two atomics per block -- one per wave on the
+    // same two words took longer than the rest of the kernel)
+    uint32_t n_own = 0, n_unc = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m_rows; r += (int64_t)gridDim.x * 256) {
+        const int32_t local = owned[r];  // (row of sub_xyz; with gidx == NULL also the index in the whole cloud)
         const double z = (double)sub_xyz[3 * (size_t)local + 2];
-        own = z >= own_lo && z < own_hi;
-        if (!own) {
+        if (!(z >= own_lo && z < own_hi)) {
             owned[r] = -1;
-        } else {
-            const int32_t g = gidx[local];
-            owned[r] = g;
-            const int c = cnt ? cnt[r] : k;
-            // no point outside the subset is closer than the nearer open face
-            const double margin = fmin(z - open_lo, open_hi - z);  // (+inf where both faces are the cloud's own ends)
-            const double lim = margin < INFINITY ? margin * margin * (1.0 - 1e-9) : INFINITY;
-            if (c >= k) {
-                // (fp32 rows carry the fp64 distance rounded to nearest: widened by what that can hide)
-                const double dk = (double)d2[(size_t)r * k + (k - 1)] * (sizeof(TD) == 4 ? 1.0 + 1e-6 : 1.0);
-                uncertain = !(dk <= lim);
-            } else {
-                // fewer than k found: final only if nothing can hide beyond the faces within the search radius
-                uncertain = !(lim == INFINITY || (radius2 >= 0.0 && radius2 <= lim));
-            }
-            if (avg_full && avg_rows) avg_full[g] = avg_rows[r];
+            continue;
         }
+        const int32_t g = gidx ? gidx[local] : local;
+        owned[r] = g;
+        n_own++;
+        const int c = cnt ? cnt[r] : k;
+        // no point outside the subset is closer than the nearer open face
+        const double margin = fmin(z - open_lo, open_hi - z);  // (+inf where both faces are the cloud's own ends)
+        const double lim = margin < INFINITY ? margin * margin * (1.0 - 1e-9) : INFINITY;
+        bool uncertain;
+        if (c >= k) {
+            // (fp32 rows carry the fp64 distance rounded to nearest: widened by what that can hide)
+            const double dk = (double)d2[(size_t)r * k + (k - 1)] * (sizeof(TD) == 4 ? 1.0 + 1e-6 : 1.0);
+            uncertain = !(dk <= lim);
+        } else {
+            // fewer than k found: final only if nothing can hide beyond the faces within the search radius
+            uncertain = !(lim == INFINITY || (radius2 >= 0.0 && radius2 <= lim));
+        }
+        n_unc += uncertain ? 1u : 0u;
+        if (avg_full && avg_rows) avg_full[g] = avg_rows[r];
     }
-    const unsigned long long mo = __ballot(own), mu = __ballot(uncertain);
-    if ((threadIdx.x & (PC_WAVE - 1)) == 0) {
-        if (mo) atomicAdd(&counts[0], (unsigned long long)__popcll(mo));
-        if (mu) atomicAdd(&counts[1], (unsigned long long)__popcll(mu));
-    }
+    __shared__ uint32_t part[2];
+    if (threadIdx.x < 2) part[threadIdx.x] = 0u;
+    __syncthreads();
+    if (n_own) atomicAdd(&part[0], n_own);
+    if (n_unc) atomicAdd(&part[1], n_unc);
+    __syncthreads();
+    if (threadIdx.x < 2 && part[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)part[threadIdx.x]);
 }
 
 }  // namespace
@@ -185,7 +200,7 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
                               int64_t *n_uncertain, void *stream) {
     PcLock lock(ctx, stream);
     if (!ctx || m_rows < 0 || k < 1 || k > PC_MAX_K || !n_own || !n_uncertain ||
-        (m_rows > 0 && (!sub_xyz_dev || !sub_index_dev || !d2_dev || !owned_dev)) || (dtype != PC_F32 && dtype != PC_F64) ||
+        (m_rows > 0 && (!sub_xyz_dev || !d2_dev || !owned_dev)) || (dtype != PC_F32 && dtype != PC_F64) ||
         (d2_dtype != PC_F32 && d2_dtype != PC_F64))
         return pc_fail(ctx, PC_BAD_ARG, "pc_slab_finish");
     PC_HIP(hipSetDevice(ctx->device));
@@ -195,10 +210,10 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
     Scratch counts(ctx, 2 * sizeof(unsigned long long));
     if (!counts.ok()) return pc_fail(ctx, PC_NOMEM, "slab counts");
     PC_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned long long), st));
-    const unsigned nb = (unsigned)((m_rows + 255) / 256);
+    const unsigned nb = (unsigned)std::min<int64_t>((m_rows + 255) / 256, 2048);
     const double r2 = radius >= 0 ? radius * radius : -1.0;
     unsigned long long *c = counts.as<unsigned long long>();
-    if (idx_dev)
+    if (idx_dev && sub_index_dev)
         hipLaunchKernelGGL(k_slab_translate, dim3((unsigned)((m_rows * k + 255) / 256)), dim3(256), 0, st, idx_dev, m_rows * k,
                            sub_index_dev);
 #define PC_SLAB_FINISH(T, TD)                                                                                             \
@@ -220,5 +235,25 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
     PC_HIP(hipStreamSynchronize(st));
     *n_own = (int64_t)hp[0];
     *n_uncertain = (int64_t)hp[1];
+    return PC_OK;
+}
+
+extern "C" int pc_grid_relabel(pc_ctx *ctx, pc_grid *grid, const int32_t *labels_dev, int64_t index_space, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || !grid || (grid->n > 0 && !labels_dev) || index_space < grid->n || index_space > INT32_MAX || grid->finer ||
+        grid->index_space > 0)
+        return pc_fail(ctx, PC_BAD_ARG, "pc_grid_relabel");
+    PC_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (pc_grid *l = grid; l; l = l->coarse) {
+        l->index_space = index_space;
+        if (l->n == 0) continue;
+        const unsigned nb = (unsigned)((l->n + 255) / 256);
+        if (l->dtype == PC_F32)
+            hipLaunchKernelGGL(k_relabel<Rec32>, dim3(nb), dim3(256), 0, st, (Rec32 *)l->rec, l->perm, l->n, labels_dev);
+        else
+            hipLaunchKernelGGL(k_relabel<Rec64>, dim3(nb), dim3(256), 0, st, (Rec64 *)l->rec, l->perm, l->n, labels_dev);
+    }
+    PC_HIP(hipGetLastError());
     return PC_OK;
 }

@@ -442,7 +442,10 @@ class HipEngine:
             gather = self.lib.pc_gather_rows_f32 if t.dtype == torch.float32 else self.lib.pc_gather_rows
             self._check(gather(self.ctx, _ptr(t), _ptr(gidx), m, _ptr(xyz), self.stream()), "pc_gather_rows")
             lap("gather")
-            sub = (gidx, xyz, DeviceGrid(self, xyz, m, k) if m > 0 else None)
+            g = DeviceGrid(self, xyz, m, k) if m > 0 else None
+            if g is not None:  # results in indices of the whole cloud from here on
+                self._check(self.lib.pc_grid_relabel(self.ctx, g.h, _ptr(gidx), n, self.stream()), "pc_grid_relabel")
+            sub = (gidx, xyz, g)
             cache[key] = sub
             lap("index")
         gidx, xyz, g = sub
@@ -470,7 +473,7 @@ class HipEngine:
             # faces of the subset beyond which the cloud goes on
             open_lo = float(lo) if lo > mn[2] else -np.inf
             open_hi = float(hi) if hi <= mx[2] else np.inf
-            self._check(self.lib.pc_slab_finish(self.ctx, _ptr(xyz), self._dt(xyz), _ptr(gidx), rows, int(k), float(radius),
+            self._check(self.lib.pc_slab_finish(self.ctx, _ptr(t), self._dt(t), None, rows, int(k), float(radius),
                                                 _ptr(out["idx"]), _ptr(out["d2"]), self._dt(out["d2"]), _ptr(out["cnt"]),
                                                 _ptr(out["owned"]), float(own_lo), float(own_hi), open_lo, open_hi,
                                                 _ptr(out.get("avg")), _ptr(avg_full), C.byref(n_own), C.byref(n_unc),
