@@ -115,11 +115,12 @@ def sor_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, wor
     return (yield from _filter_core(engine, pts, cache, k, std_ratio, sh, b, e))
 
 
-def pipeline_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, **search_kw):
+def pipeline_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, want_normals: bool = True,
+                   **search_kw):
     """kNN rows + statistical filter + normals from ONE search of the rank's slice: returns the slice's
     outputs (rows, mean distances, normals, owned indices), the kept indices and the statistics."""
     b, e = shard_positions(len(pts), rank, world)
-    sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_rows=True, want_avg=True, want_normals=True, **search_kw)
+    sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_rows=True, want_avg=True, want_normals=want_normals, **search_kw)
     kept, stats = yield from _filter_core(engine, pts, cache, k, std_ratio, sh, b, e)
     return sh, kept, stats
 
@@ -167,7 +168,8 @@ def slab_cuts(engine, pts, cache: dict, k: int, world: int):
     return cuts, halo
 
 
-def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, **search_kw):
+def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, want_normals: bool = True,
+                        **search_kw):
     """``pipeline_steps`` with an index of the rank's own slab instead of a replicated one: rows, mean distances
     and normals of the rank's z interval from ONE search of the slab, then one exchange -- the mean distances
     put together (each rank fills its own rows of a zeroed array: adding the others' zeros is exact), with the
@@ -176,16 +178,16 @@ def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank
     ``owned`` < 0 belong to a neighbouring rank."""
     plan = slab_cuts(engine, pts, cache, k, world)
     if plan is None:
-        return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, **search_kw))
+        return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, want_normals, **search_kw))
     cuts, halo = plan
     n = len(pts)
     box = engine.zeros_f64(n + 1)
-    sh = engine.slab_search(pts, cache, k, -1.0, cuts[rank], cuts[rank + 1], halo, want_avg=True, want_normals=True,
+    sh = engine.slab_search(pts, cache, k, -1.0, cuts[rank], cuts[rank + 1], halo, want_avg=True, want_normals=want_normals,
                             avg_full=box, **search_kw)
     box[n] = float(sh["n_uncertain"])
     box = yield box
     if float(box[n]) != 0.0:
-        return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, **search_kw))
+        return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, want_normals, **search_kw))
     kept, stats = engine.sor_from_avg(box, n, std_ratio)
     return sh, kept, stats
 
