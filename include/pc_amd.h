@@ -155,10 +155,12 @@ int64_t pc_sor_chunks(int64_t n);
 int pc_sor_chunk_sums(pc_ctx *ctx, const pc_grid *grid, const double *avg_dev, int compact, int64_t s_begin, int64_t s_end,
                       int what, double mean, double *partials_dev, void *stream);
 int pc_sor_chunk_finish(pc_ctx *ctx, const double *partials_dev, int64_t nchunks, double out[2], void *stream);
-/* The kept mask of the statistical filter as a bit mask over original indices (bit i of the mask = point i is kept;
- * pc_mask_bytes(n) bytes, a multiple of 4, 4-byte aligned, zeroed by the caller): pc_sor_mask_scatter sets the bits of
- * the m compact rows of a rank (avg[i] > 0 && avg[i] < threshold -> bit owned[i]); the ranks' masks are added
- * elementwise (their bits are disjoint: the sum is the union); pc_mask_select: ascending indices of the set bits. */
+/* The outcome of the statistical filter as a bit mask over original indices (bit i set = point i is REMOVED: a filter
+ * removes a few per cent of the points, so marking those costs a tenth of marking the kept; pc_mask_bytes(n) bytes, a
+ * multiple of 4, 4-byte aligned, zeroed by the caller): pc_sor_mask_scatter sets the bits of those of a rank's m compact
+ * rows that fail avg[i] > 0 && avg[i] < threshold (bit owned[i]; rows with owned[i] < 0 are skipped); the ranks' masks
+ * are added elementwise (their bits are disjoint: the sum is the union); pc_mask_select: ascending indices below n of
+ * the CLEAR bits, i.e. the kept points. */
 int64_t pc_mask_bytes(int64_t n);
 int pc_sor_mask_scatter(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, double threshold,
                         uint8_t *mask_dev, void *stream);

@@ -324,17 +324,17 @@ __global__ __launch_bounds__(256) void k_mask_scatter(const double *__restrict__
                                                        int64_t m, double thr, uint32_t *__restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < m) {
+        // (the removed points are marked, not the kept ones: a filter removes a few per cent, and every mark is an
+        // atomic on a random word -- 10 M points: 0.37 ms marking the kept, 0.02 ms marking the removed)
         const double v = avg[i];
-        if (v > 0 && v < thr) {
-            const uint32_t o = (uint32_t)owned[i];
-            atomicOr(&mask[o >> 5], 1u << (o & 31u));
-        }
+        const int32_t o = owned[i];
+        if (!(v > 0 && v < thr) && o >= 0) atomicOr(&mask[(uint32_t)o >> 5], 1u << ((uint32_t)o & 31u));
     }
 }
 
 __global__ __launch_bounds__(256) void k_bits_to_flags(const uint32_t *__restrict__ mask, int64_t n, uint8_t *__restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) flags[i] = (mask[i >> 5] >> (i & 31)) & 1u;
+    if (i < n) flags[i] = ((mask[i >> 5] >> (i & 31)) & 1u) ^ 1u;  // (a set bit: removed)
 }
 
 int sor_reduce(pc_ctx *ctx, int what, const double *avg, int64_t n, double mean, double out[2], hipStream_t st) {

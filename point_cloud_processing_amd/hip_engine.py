@@ -515,7 +515,7 @@ class HipEngine:
         return float(out[0]), float(out[1])
 
     def mask_scatter(self, avg, owned, thr, n) -> torch.Tensor:
-        mask = torch.zeros((int(self.lib.pc_mask_bytes(n)),), dtype=torch.uint8, device=self.device)  # one bit per point
+        mask = torch.zeros((int(self.lib.pc_mask_bytes(n)),), dtype=torch.uint8, device=self.device)  # one bit per point, set = removed
         self._check(self.lib.pc_sor_mask_scatter(self.ctx, _ptr(avg), _ptr(owned), avg.numel(), float(thr), _ptr(mask),
                                                  self.stream()), "pc_sor_mask_scatter")
         return mask
