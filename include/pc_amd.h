@@ -228,10 +228,12 @@ int pc_gather_rows_f32(pc_ctx *ctx, const float *src_dev, const int32_t *idx_dev
  * and lets pc_slab_finish translate the rows back to indices of the whole cloud and count the answers that the
  * subset cannot vouch for (k-th distance beyond the nearer open face of the slab): those are repeated on a
  * wider slab or a full index, so results stay exact. */
-/* Counts of the n points per bin of [lo, hi] along axis (nbins <= 4096 equal bins, ends clamped), into host
- * memory: what the cuts between the ranks' intervals are chosen from.  Synchronises the stream. */
-int pc_axis_histogram(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi, int nbins,
-                      uint32_t *out_counts, void *stream);
+/* Counts of the n points per bin of [lo, hi] along axis (nbins <= 4096 equal bins, ends clamped; lo / hi point to one
+ * value each), or, with axis < 0, along all three axes at once (lo / hi point to three values, out_counts holds
+ * 3 * nbins counters, axis-major), into host memory: what the cuts between the ranks' intervals and the extent of the
+ * cloud's bulk are read from.  Synchronises the stream. */
+int pc_axis_histogram(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, const double *lo, const double *hi,
+                      int nbins, uint32_t *out_counts, void *stream);
 /* Ascending indices of the points with lo <= coordinate < hi along axis (+-inf allowed); out_index_dev holds up to n
  * entries, *m receives their number.  Synchronises the stream. */
 int pc_select_slab(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi,
@@ -253,12 +255,28 @@ int pc_grid_relabel(pc_ctx *ctx, pc_grid *grid, const int32_t *labels_dev, int64
  * z faces beyond which the cloud has more points (-inf / +inf where it has none).  avg_full (may be NULL, else n
  * doubles): avg_rows of the own rows written at their index in the whole cloud.  *n_own: own rows; *n_uncertain:
  * own rows whose k-th squared distance is not below the squared distance to the nearer open face (or that found
- * fewer than k although points may hide beyond a face within the radius).  cnt_dev may be NULL (every row has k).
+ * fewer than k although points may hide beyond a face within the radius); out_uncertain_rows (may be NULL, else m_rows
+ * entries): those rows, ascending.  cnt_dev may be NULL (every row has k).
  * Synchronises the stream. */
 int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, const int32_t *sub_index_dev, int64_t m_rows, int k,
                    double radius, int32_t *idx_dev, const void *d2_dev, int d2_dtype, const int32_t *cnt_dev,
                    int32_t *owned_dev, double own_lo, double own_hi, double open_lo, double open_hi,
-                   const double *avg_rows_dev, double *avg_full_dev, int64_t *n_own, int64_t *n_uncertain, void *stream);
+                   const double *avg_rows_dev, double *avg_full_dev, int32_t *out_uncertain_rows_dev, int64_t *n_own,
+                   int64_t *n_uncertain, void *stream);
+/* The repeat of the answers no slab could vouch for: every rank answers ALL of them against its own slab (pc_knn with
+ * the queries as an array), the rows travel, and pc_merge_rows puts them together: idx_all / d2_all hold world x nq x k
+ * entries (rank-major; each row ascending in (d2, index), cnt_all its valid entries: world x nq), the outputs the nq
+ * merged rows -- the k nearest of the union in the same order, a point that two ranks index (halos overlap) taken once.
+ * Exact because the ranks' subsets cover the cloud: a true neighbour is among the k nearest of any subset holding it. */
+int pc_merge_rows(pc_ctx *ctx, int world, int64_t nq, int k, const int32_t *idx_all_dev, const double *d2_all_dev,
+                  const int32_t *cnt_all_dev, int32_t *out_idx_dev, double *out_d2_dev, int32_t *out_cnt_dev, void *stream);
+/* The searches' consumers for finished rows: out_avg[q] = mean neighbour distance (remove_statistical_outlier,
+ * filtering_adapter.py:91) and out_normals[q] = PCA normal (estimate_normals, pointcloud_preprocess.py:109-114) of query
+ * point query_index[q] of the cloud xyz from its row idx[q] (cnt[q] valid entries, indices into xyz), computed as the
+ * fused search computes them.  Either output may be NULL. */
+int pc_rows_consumers(pc_ctx *ctx, const void *xyz_dev, int dtype, const int32_t *query_index_dev, int64_t nq, int k,
+                      const int32_t *idx_dev, const int32_t *cnt_dev, double *out_avg_dev, double *out_normals_dev,
+                      void *stream);
 
 /* PointCloud.orient_normals_consistent_tangent_plane(k) (app/Core/pointcloud_preprocess.py:115): turns the
  * n normals (n x 3 fp64, in place) so that they agree along the minimum spanning tree of the neighbour graph

@@ -120,10 +120,13 @@ class OracleEngine:
             out["normals"] = np.ascontiguousarray(O.normals(pts, k, radius)[b:e])
         return out
 
-    def axis_histogram(self, pts, cache, axis, lo, hi, nbins):
-        inv = nbins / (hi - lo) if hi > lo else 0.0
-        b = np.clip(np.floor((np.asarray(pts)[:, axis] - lo) * inv), 0, nbins - 1).astype(np.int64)
-        return np.bincount(b, minlength=nbins).astype(np.uint32)
+    def axes_histogram(self, pts, cache, lo, hi, nbins):
+        out = np.zeros((3, nbins), dtype=np.uint32)
+        for a in range(3):
+            inv = nbins / (hi[a] - lo[a]) if hi[a] > lo[a] else 0.0
+            b = np.clip(np.floor((np.asarray(pts)[:, a] - lo[a]) * inv), 0, nbins - 1).astype(np.int64)
+            out[a] = np.bincount(b, minlength=nbins)
+        return out
 
     def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False, avg_full=None):
         pts = np.asarray(pts, dtype=np.float64)
@@ -143,7 +146,10 @@ class OracleEngine:
         full = cnt >= k
         dk = np.where(full, d2[:, k - 1], np.inf)
         r2 = radius * radius if radius >= 0 else -1.0
-        out["n_uncertain"] = int(np.where(full, ~(dk <= lim), ~(np.isinf(lim) | ((r2 >= 0) & (r2 <= lim)))).sum())
+        unc = np.where(full, ~(dk <= lim), ~(np.isinf(lim) | ((r2 >= 0) & (r2 <= lim))))
+        out["n_uncertain"] = int(unc.sum())
+        out["uncertain_rows"] = np.nonzero(unc)[0]
+        out["slab_key"] = (float(lo), float(hi))
         if want_avg or avg_full is not None:
             out["avg"] = np.ascontiguousarray(O.sor_avg(sub, k)[own])
             if avg_full is not None:
@@ -154,6 +160,43 @@ class OracleEngine:
 
     def zeros_f64(self, m):
         return np.zeros(m)
+
+    def zeros(self, shape, kind):
+        return np.zeros(shape, dtype=np.int32 if kind == "i32" else np.float64)
+
+    @staticmethod
+    def cast_like(x, like):
+        return x.astype(like.dtype)
+
+    def slab_requery(self, pts, cache, slab_key, qidx, k):
+        pts = np.asarray(pts, dtype=np.float64)
+        lo, hi = slab_key
+        gidx = np.nonzero((pts[:, 2] >= lo) & (pts[:, 2] < hi))[0]
+        idx, d2, cnt = O.knn(np.ascontiguousarray(pts[gidx]), np.ascontiguousarray(pts[np.asarray(qidx)]), k)
+        return np.where(idx >= 0, gidx[np.maximum(idx, 0)], -1).astype(np.int32), d2, cnt.astype(np.int32)
+
+    def merge_rows(self, idx_all, d2_all, cnt_all):
+        world, m, k = idx_all.shape
+        idx = np.full((m, k), -1, dtype=np.int32)
+        d2 = np.full((m, k), np.inf)
+        cnt = np.zeros(m, dtype=np.int32)
+        for q in range(m):
+            ent = sorted({(float(d2_all[w, q, s]), int(idx_all[w, q, s])) for w in range(world) for s in range(int(cnt_all[w, q]))})[:k]
+            cnt[q] = len(ent)
+            for s, (d, i) in enumerate(ent):
+                idx[q, s], d2[q, s] = i, d
+        return idx, d2, cnt
+
+    def rows_consumers(self, pts, cache, qidx, idx, cnt, want_normals):
+        pts = np.asarray(pts, dtype=np.float64)
+        k = idx.shape[1]
+        avg = np.full(len(qidx), -1.0)
+        for q, me in enumerate(np.asarray(qidx)):
+            if cnt[q] > 0:
+                d = pts[idx[q, :cnt[q]]] - pts[me]
+                avg[q] = np.sqrt((d * d).sum(1)).sum() / cnt[q]
+        nrm = np.ascontiguousarray(O.normals(pts, k)[np.asarray(qidx)]) if want_normals else None
+        return avg, nrm
 
     def sor_from_avg(self, avg, n, std_ratio):
         avg = np.asarray(avg)[:n]

@@ -59,12 +59,14 @@ SYMBOLS = [
     ("pc_scatter_rows", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     ("pc_gather_rows_f32", _i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     ("pc_count_select", _i32, [_vp, _vp, _i64, _i32, _vp, _vp, _pi64, _vp]),
-    ("pc_axis_histogram", _i32, [_vp, _vp, _i32, _i64, _i32, _dbl, _dbl, _i32, _vp, _vp]),
+    ("pc_axis_histogram", _i32, [_vp, _vp, _i32, _i64, _i32, _pd, _pd, _i32, _vp, _vp]),
     ("pc_select_slab", _i32, [_vp, _vp, _i32, _i64, _i32, _dbl, _dbl, _vp, _pi64, _vp]),
     ("pc_grid_axis_range", _i32, [_vp, _vp, _dbl, _dbl, _pi64, _pi64, _vp]),
     ("pc_grid_relabel", _i32, [_vp, _vp, _vp, _i64, _vp]),
     ("pc_slab_finish", _i32, [_vp, _vp, _i32, _vp, _i64, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl,
-                              _vp, _vp, _pi64, _pi64, _vp]),
+                              _vp, _vp, _vp, _pi64, _pi64, _vp]),
+    ("pc_merge_rows", _i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("pc_rows_consumers", _i32, [_vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     ("pc_orient_normals", _i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     ("pc_icp_point_to_plane_terms", _i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
     ("pc_transform", _i32, [_vp, _vp, _i64, _vp, _vp]),

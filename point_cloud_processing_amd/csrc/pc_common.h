@@ -20,6 +20,7 @@ struct PcKnobs {
     bool debug = false;            // PC_AMD_DEBUG: per-pass log on stderr
     double cell_scale = 0.0;       // PC_AMD_CELL_SCALE: scales the automatic cell edge (0: off)
     bool no_halves = false;        // PC_AMD_NO_HALVES
+    double seed_scale = 0.0;       // PC_AMD_SEED_SCALE: the tile kernel's starting threshold over the certification bound (0: default)
     int uneven_cap = 0;            // PC_AMD_UNEVEN_CAP: candidates an uneven level's tile stages (0: default)
     int tile_waves = 0;            // PC_AMD_TILE_WAVES (0: default)
     int tile[3] = {0, 0, 0};       // PC_AMD_TILE "tx,ty,tz" (0: automatic)

@@ -73,6 +73,7 @@ PcKnobs pc_read_knobs() {
         k.debug = on("PC_AMD_DEBUG");
         if (const char *e = getenv("PC_AMD_CELL_SCALE")) k.cell_scale = atof(e);
         k.no_halves = on("PC_AMD_NO_HALVES");
+        if (const char *e = getenv("PC_AMD_SEED_SCALE")) k.seed_scale = atof(e);
         k.uneven_cap = (int)num("PC_AMD_UNEVEN_CAP", 0);
         k.tile_waves = (int)num("PC_AMD_TILE_WAVES", 0);
         if (const char *e = getenv("PC_AMD_TILE")) {

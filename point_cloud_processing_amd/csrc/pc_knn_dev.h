@@ -150,6 +150,8 @@ struct ScanArgs {
     // ring of the first block of a listed query that comes without a bound: 2 where a tile pass of the same
     // (only) level has looked at the query's 3 x 3 x 3 cells already and found them wanting, else 1
     int first_ring;
+    // tile kernel: the threshold of the filter starts at this multiple of the certification bound (squared distances)
+    double seed_scale;
 };
 
 // an open query (flag set) that the pass of flag_max answers

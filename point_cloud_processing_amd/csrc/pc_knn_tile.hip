@@ -368,6 +368,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     }
     A.s_end = A.s_begin + A.nq;
     A.flag_cap = (uint32_t)A.nq;
+    A.seed_scale = ctx->knobs.seed_scale >= 1.001 ? ctx->knobs.seed_scale : 1.001;
     // [counts (256 B)] [list 1] [upper bounds 1] [list 2] [per-point bounds] [per-point flags]; the
     // block returns to the pool when this function ends, which is safe because everything that
     // touches it is ordered on `st`

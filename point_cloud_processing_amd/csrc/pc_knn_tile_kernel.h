@@ -487,7 +487,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                     const double rs = sqrt(seed) + 4.76837158203125e-07 * bext;
                     seed = rs * rs;
                 }
-                thr0 = min(KEY_INF, __float_as_uint((float)(seed * 1.001)) & ~ORD_MASK);
+                thr0 = min(KEY_INF, __float_as_uint((float)(seed * A.seed_scale)) & ~ORD_MASK);
             }
             thr = thr0;
         }

@@ -17,20 +17,27 @@ namespace {
 
 constexpr int HIST_MAX_BINS = 4096;
 
+// axis 0..2: one histogram; axis < 0: one per axis (3 * nbins counters), from one pass over the cloud
 template <typename T>
-__global__ __launch_bounds__(256) void k_axis_hist(const T *__restrict__ xyz, int64_t n, int axis, double lo,
-                                                   double inv_width, int nbins, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t h[HIST_MAX_BINS];
-    for (int b = threadIdx.x; b < nbins; b += 256) h[b] = 0u;
+__global__ __launch_bounds__(256) void k_axis_hist(const T *__restrict__ xyz, int64_t n, int axis, double lo0, double lo1,
+                                                   double lo2, double iw0, double iw1, double iw2, int nbins,
+                                                   uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[3 * HIST_MAX_BINS];
+    const int na = axis < 0 ? 3 : 1;
+    for (int b = threadIdx.x; b < na * nbins; b += 256) h[b] = 0u;
     __syncthreads();
+    const double lo[3] = {lo0, lo1, lo2}, iw[3] = {iw0, iw1, iw2};
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const double t = floor(((double)xyz[3 * i + axis] - lo) * inv_width);
-        const int b = !(t > 0.0) ? 0 : (t >= (double)nbins ? nbins - 1 : (int)t);
-        atomicAdd(&h[b], 1u);
+        for (int a = 0; a < na; a++) {
+            const int ax = axis < 0 ? a : axis;
+            const double t = floor(((double)xyz[3 * i + ax] - lo[ax]) * iw[ax]);
+            const int b = !(t > 0.0) ? 0 : (t >= (double)nbins ? nbins - 1 : (int)t);
+            atomicAdd(&h[a * nbins + b], 1u);
+        }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += 256)
+    for (int b = threadIdx.x; b < na * nbins; b += 256)
         if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 
@@ -82,7 +89,8 @@ __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_x
                                                      const TD *__restrict__ d2, const int32_t *__restrict__ cnt,
                                                      int32_t *__restrict__ owned, double own_lo, double own_hi,
                                                      double open_lo, double open_hi, const double *__restrict__ avg_rows,
-                                                     double *__restrict__ avg_full, unsigned long long *__restrict__ counts) {
+                                                     double *__restrict__ avg_full, uint8_t *__restrict__ unc_flags,
+                                                     unsigned long long *__restrict__ counts) {
     // (grid-stride rows, counts summed per thread, then per block: two atomics per block -- one per wave on the
     // same two words took longer than the rest of the kernel)
     uint32_t n_own = 0, n_unc = 0;
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_x
         const double z = (double)sub_xyz[3 * (size_t)local + 2];
         if (!(z >= own_lo && z < own_hi)) {
             owned[r] = -1;
+            if (unc_flags) unc_flags[r] = 0;
             continue;
         }
         const int32_t g = gidx ? gidx[local] : local;
@@ -110,6 +119,7 @@ __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_x
             uncertain = !(lim == INFINITY || (radius2 >= 0.0 && radius2 <= lim));
         }
         n_unc += uncertain ? 1u : 0u;
+        if (unc_flags) unc_flags[r] = uncertain ? 1 : 0;
         if (avg_full && avg_rows) avg_full[g] = avg_rows[r];
     }
     __shared__ uint32_t part[2];
@@ -121,31 +131,106 @@ __global__ __launch_bounds__(256) void k_slab_finish(const T *__restrict__ sub_x
     if (threadIdx.x < 2 && part[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)part[threadIdx.x]);
 }
 
+// The ranks' answers to the same queries merged: rank w's row of query q holds its cnt nearest points in ascending
+// (d2, index) order; the union's k nearest in the same order are the exact answer when the ranks' subsets cover the
+// cloud.  A point indexed by two ranks (halos overlap) appears twice with the same key: taken once.
+__global__ __launch_bounds__(64) void k_merge_rows(int world, int64_t nq, int k, const int32_t *__restrict__ idx_all,
+                                                   const double *__restrict__ d2_all, const int32_t *__restrict__ cnt_all,
+                                                   int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
+                                                   int32_t *__restrict__ out_cnt) {
+    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    int cur[PC_MAX_K];  // (one cursor per rank: world <= PC_MAX_K)
+    for (int w = 0; w < world; w++) cur[w] = 0;
+    int got = 0;
+    int32_t last = -1;
+    while (got < k) {
+        int best = -1;
+        double bd = INFINITY;
+        int32_t bi = 0x7fffffff;
+        for (int w = 0; w < world; w++) {
+            if (cur[w] >= cnt_all[(int64_t)w * nq + q]) continue;
+            const int64_t at = ((int64_t)w * nq + q) * k + cur[w];
+            const double d = d2_all[at];
+            const int32_t i = idx_all[at];
+            if (best < 0 || d < bd || (d == bd && i < bi)) {
+                best = w;
+                bd = d;
+                bi = i;
+            }
+        }
+        if (best < 0) break;
+        cur[best]++;
+        if (got > 0 && bi == last) continue;  // the same point from another rank's halo
+        out_idx[q * k + got] = bi;
+        out_d2[q * k + got] = bd;
+        last = bi;
+        got++;
+    }
+    for (int s = got; s < k; s++) {
+        out_idx[q * k + s] = -1;
+        out_d2[q * k + s] = INFINITY;
+    }
+    out_cnt[q] = got;
+}
+
+// mean neighbour distance and normal of listed queries from their finished rows (the searches' own consumers,
+// fed from the rows instead of a candidate block)
+template <typename T>
+__global__ __launch_bounds__(64) void k_rows_consumers(ScanArgs A, const T *__restrict__ xyz, const int32_t *__restrict__ qidx,
+                                                       int64_t nq, const int32_t *__restrict__ idx,
+                                                       const int32_t *__restrict__ cnt) {
+    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    const int32_t me = qidx[q];
+    const double qx = (double)xyz[3 * (size_t)me], qy = (double)xyz[3 * (size_t)me + 1], qz = (double)xyz[3 * (size_t)me + 2];
+    const int k = A.k;
+    emit_result<M_ALL>(A, q, cnt[q], [&](int s, double &d, double &x, double &y, double &z, int32_t &id) {
+        id = idx[q * k + s];
+        x = (double)xyz[3 * (size_t)id];
+        y = (double)xyz[3 * (size_t)id + 1];
+        z = (double)xyz[3 * (size_t)id + 2];
+        const double dx = qx - x, dy = qy - y, dz = qz - z;
+        d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+    });
+}
+
 }  // namespace
 
-extern "C" int pc_axis_histogram(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, double lo, double hi,
-                                 int nbins, uint32_t *out_counts, void *stream) {
+extern "C" int pc_axis_histogram(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, int axis, const double *lo,
+                                 const double *hi, int nbins, uint32_t *out_counts, void *stream) {
     PcLock lock(ctx, stream);
-    if (!ctx || n < 0 || (n > 0 && !xyz_dev) || axis < 0 || axis > 2 || nbins < 1 || nbins > HIST_MAX_BINS || !out_counts ||
-        !(hi >= lo) || (dtype != PC_F32 && dtype != PC_F64))
+    if (!ctx || n < 0 || (n > 0 && !xyz_dev) || axis > 2 || nbins < 1 || nbins > HIST_MAX_BINS || !out_counts || !lo || !hi ||
+        (dtype != PC_F32 && dtype != PC_F64))
         return pc_fail(ctx, PC_BAD_ARG, "pc_axis_histogram");
+    const int na = axis < 0 ? 3 : 1;
+    double l[3] = {0, 0, 0}, iw[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++) {
+        if (axis >= 0 && a != axis) continue;
+        const int j = axis < 0 ? a : 0;  // (one axis: lo[0] / hi[0]; all axes: lo[a] / hi[a])
+        if (!(hi[j] >= lo[j])) return pc_fail(ctx, PC_BAD_ARG, "pc_axis_histogram: hi < lo");
+        l[a] = lo[j];
+        iw[a] = hi[j] > lo[j] ? (double)nbins / (hi[j] - lo[j]) : 0.0;
+    }
     PC_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    for (int b = 0; b < nbins; b++) out_counts[b] = 0u;
+    for (int b = 0; b < na * nbins; b++) out_counts[b] = 0u;
     if (n == 0) return PC_OK;
-    Scratch h(ctx, sizeof(uint32_t) * (size_t)nbins);
+    const size_t bytes = sizeof(uint32_t) * (size_t)(na * nbins);
+    Scratch h(ctx, bytes);
     if (!h.ok()) return pc_fail(ctx, PC_NOMEM, "histogram");
-    PC_HIP(hipMemsetAsync(h.p, 0, sizeof(uint32_t) * (size_t)nbins, st));
-    const double inv_width = hi > lo ? (double)nbins / (hi - lo) : 0.0;
+    PC_HIP(hipMemsetAsync(h.p, 0, bytes, st));
     const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
     if (dtype == PC_F32)
-        hipLaunchKernelGGL(k_axis_hist<float>, dim3(nb), dim3(256), 0, st, (const float *)xyz_dev, n, axis, lo, inv_width,
-                           nbins, h.as<uint32_t>());
+        hipLaunchKernelGGL(k_axis_hist<float>, dim3(nb), dim3(256), 0, st, (const float *)xyz_dev, n, axis, l[0], l[1], l[2],
+                           iw[0], iw[1], iw[2], nbins, h.as<uint32_t>());
     else
-        hipLaunchKernelGGL(k_axis_hist<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz_dev, n, axis, lo, inv_width,
-                           nbins, h.as<uint32_t>());
+        hipLaunchKernelGGL(k_axis_hist<double>, dim3(nb), dim3(256), 0, st, (const double *)xyz_dev, n, axis, l[0], l[1], l[2],
+                           iw[0], iw[1], iw[2], nbins, h.as<uint32_t>());
     PC_HIP(hipGetLastError());
-    PC_HIP(hipMemcpyAsync(out_counts, h.p, sizeof(uint32_t) * (size_t)nbins, hipMemcpyDeviceToHost, st));
+    PC_HIP(hipMemcpyAsync(out_counts, h.p, bytes, hipMemcpyDeviceToHost, st));
     PC_HIP(hipStreamSynchronize(st));
     return PC_OK;
 }
@@ -196,8 +281,8 @@ extern "C" int pc_grid_axis_range(pc_ctx *ctx, const pc_grid *grid, double lo, d
 extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, const int32_t *sub_index_dev, int64_t m_rows,
                               int k, double radius, int32_t *idx_dev, const void *d2_dev, int d2_dtype,
                               const int32_t *cnt_dev, int32_t *owned_dev, double own_lo, double own_hi, double open_lo,
-                              double open_hi, const double *avg_rows_dev, double *avg_full_dev, int64_t *n_own,
-                              int64_t *n_uncertain, void *stream) {
+                              double open_hi, const double *avg_rows_dev, double *avg_full_dev,
+                              int32_t *out_uncertain_rows_dev, int64_t *n_own, int64_t *n_uncertain, void *stream) {
     PcLock lock(ctx, stream);
     if (!ctx || m_rows < 0 || k < 1 || k > PC_MAX_K || !n_own || !n_uncertain ||
         (m_rows > 0 && (!sub_xyz_dev || !d2_dev || !owned_dev)) || (dtype != PC_F32 && dtype != PC_F64) ||
@@ -207,8 +292,9 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
     hipStream_t st = (hipStream_t)stream;
     *n_own = *n_uncertain = 0;
     if (m_rows == 0) return PC_OK;
-    Scratch counts(ctx, 2 * sizeof(unsigned long long));
-    if (!counts.ok()) return pc_fail(ctx, PC_NOMEM, "slab counts");
+    Scratch counts(ctx, 2 * sizeof(unsigned long long)), uflags(ctx, out_uncertain_rows_dev ? (size_t)m_rows : 0);
+    if (!counts.ok() || !uflags.ok()) return pc_fail(ctx, PC_NOMEM, "slab counts");
+    uint8_t *uf = out_uncertain_rows_dev ? uflags.as<uint8_t>() : nullptr;
     PC_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(unsigned long long), st));
     const unsigned nb = (unsigned)std::min<int64_t>((m_rows + 255) / 256, 2048);
     const double r2 = radius >= 0 ? radius * radius : -1.0;
@@ -219,7 +305,7 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
 #define PC_SLAB_FINISH(T, TD)                                                                                             \
     hipLaunchKernelGGL((k_slab_finish<T, TD>), dim3(nb), dim3(256), 0, st, (const T *)sub_xyz_dev, sub_index_dev, m_rows, k, \
                        r2, (const TD *)d2_dev, cnt_dev, owned_dev, own_lo, own_hi, open_lo, open_hi, avg_rows_dev, \
-                       avg_full_dev, c)
+                       avg_full_dev, uf, c)
     if (dtype == PC_F32 && d2_dtype == PC_F32)
         PC_SLAB_FINISH(float, float);
     else if (dtype == PC_F32)
@@ -235,6 +321,10 @@ extern "C" int pc_slab_finish(pc_ctx *ctx, const void *sub_xyz_dev, int dtype, c
     PC_HIP(hipStreamSynchronize(st));
     *n_own = (int64_t)hp[0];
     *n_uncertain = (int64_t)hp[1];
+    if (uf && *n_uncertain > 0) {  // the rows to repeat, ascending
+        int64_t listed = 0;
+        PC_TRY(pc_compact_flags(ctx, uf, m_rows, out_uncertain_rows_dev, &listed, st));
+    }
     return PC_OK;
 }
 
@@ -254,6 +344,46 @@ extern "C" int pc_grid_relabel(pc_ctx *ctx, pc_grid *grid, const int32_t *labels
         else
             hipLaunchKernelGGL(k_relabel<Rec64>, dim3(nb), dim3(256), 0, st, (Rec64 *)l->rec, l->perm, l->n, labels_dev);
     }
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+extern "C" int pc_merge_rows(pc_ctx *ctx, int world, int64_t nq, int k, const int32_t *idx_all_dev, const double *d2_all_dev,
+                             const int32_t *cnt_all_dev, int32_t *out_idx_dev, double *out_d2_dev, int32_t *out_cnt_dev,
+                             void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || world < 1 || world > PC_MAX_K || nq < 0 || k < 1 || k > PC_MAX_K ||
+        (nq > 0 && (!idx_all_dev || !d2_all_dev || !cnt_all_dev || !out_idx_dev || !out_d2_dev || !out_cnt_dev)))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_merge_rows");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (nq == 0) return PC_OK;
+    hipLaunchKernelGGL(k_merge_rows, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, world, nq, k, idx_all_dev,
+                       d2_all_dev, cnt_all_dev, out_idx_dev, out_d2_dev, out_cnt_dev);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+extern "C" int pc_rows_consumers(pc_ctx *ctx, const void *xyz_dev, int dtype, const int32_t *query_index_dev, int64_t nq, int k,
+                                 const int32_t *idx_dev, const int32_t *cnt_dev, double *out_avg_dev, double *out_normals_dev,
+                                 void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || nq < 0 || k < 1 || k > PC_MAX_K || (dtype != PC_F32 && dtype != PC_F64) ||
+        (nq > 0 && (!xyz_dev || !query_index_dev || !idx_dev || !cnt_dev)))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_rows_consumers");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (nq == 0 || (!out_avg_dev && !out_normals_dev)) return PC_OK;
+    ScanArgs A{};
+    A.k = k;
+    A.out_f64 = out_avg_dev;
+    A.out_nrm = out_normals_dev;
+    A.compact_base = -1;
+    const unsigned nb = (unsigned)((nq + 63) / 64);
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_rows_consumers<float>, dim3(nb), dim3(64), 0, (hipStream_t)stream, A, (const float *)xyz_dev,
+                           query_index_dev, nq, idx_dev, cnt_dev);
+    else
+        hipLaunchKernelGGL(k_rows_consumers<double>, dim3(nb), dim3(64), 0, (hipStream_t)stream, A, (const double *)xyz_dev,
+                           query_index_dev, nq, idx_dev, cnt_dev);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }

@@ -152,15 +152,22 @@ def slab_cuts(engine, pts, cache: dict, k: int, world: int):
     ext = np.asarray(mx, dtype=np.float64) - np.asarray(mn, dtype=np.float64)
     if n < 2 * world or not ext[2] > 0:
         return None
-    hist = np.asarray(engine.axis_histogram(pts, cache, 2, float(mn[2]), float(mx[2]), SLAB_BINS), dtype=np.int64)
-    cum = np.cumsum(hist)
-    width = ext[2] / SLAB_BINS
+    hist = np.asarray(engine.axes_histogram(pts, cache, mn, mx, SLAB_BINS), dtype=np.int64)
+    cum = np.cumsum(hist[2])
+    width = ext / SLAB_BINS
     cuts = [-np.inf]
     for r in range(1, world):
         b = int(np.searchsorted(cum, (r * n) // world))  # first bin whose running count reaches the rank's share
-        cuts.append(float(mn[2] + (b + 1) * width))
+        cuts.append(float(mn[2] + (b + 1) * width[2]))
     cuts.append(np.inf)
-    floor_ext = np.maximum(ext, 1e-3 * ext.max())
+    # the box of the cloud's bulk (all but half a per cent of the points at either end of every axis): a few stray
+    # points far out would otherwise inflate the volume, and with it the halo, until no slab is worth making
+    bulk = np.empty(3)
+    for a in range(3):
+        c = np.cumsum(hist[a])
+        b0, b1 = int(np.searchsorted(c, n // 200)), int(np.searchsorted(c, n - n // 200))
+        bulk[a] = (b1 - b0 + 1) * width[a]
+    floor_ext = np.maximum(bulk, 1e-3 * bulk.max())
     halo = SLAB_HALO * float((k * np.prod(floor_ext) / n) ** (1.0 / 3.0))
     inner = np.diff(np.array([mn[2]] + cuts[1:-1] + [mx[2]]))
     if not (np.diff(cuts[1:-1]) > 0).all() or inner.min() < 2.0 * halo:
@@ -168,14 +175,51 @@ def slab_cuts(engine, pts, cache: dict, k: int, world: int):
     return cuts, halo
 
 
+SLAB_REPEAT_MAX = 1 << 16  # answers repeated across the ranks at most; beyond, the job goes to the replicated index
+
+
+def _repeat_unvouched(engine, pts, cache: dict, k: int, sh: dict, box, rank: int, world: int, total: int, want_normals: bool):
+    """The answers no slab could vouch for, repeated exactly without any full index: the ranks put their lists of
+    such queries together, EVERY rank answers all of them against its own slab, the rows travel and are merged
+    (the slabs cover the cloud, so the k nearest of the union of the ranks' k nearest are the true neighbours).
+    Every exchange is a sum of arrays in which each rank fills its own part of zeros.  Patches the rank's rows in
+    ``sh`` and the mean distances in ``box`` (on every rank alike)."""
+    counts = engine.zeros((world,), "f64")
+    counts[rank] = float(sh["n_uncertain"])
+    counts = yield counts
+    counts = np.asarray(engine.to_host(counts)).astype(np.int64)
+    at = int(counts[:rank].sum())
+    mine = slice(at, at + int(counts[rank]))
+    rows = sh["uncertain_rows"]
+    queries = engine.zeros((total,), "i32")
+    queries[mine] = sh["owned"][rows]
+    queries = yield queries
+    ridx, rd2, rcnt = engine.slab_requery(pts, cache, sh["slab_key"], queries, k)
+    all_idx, all_d2, all_cnt = engine.zeros((world, total, k), "i32"), engine.zeros((world, total, k), "f64"), engine.zeros((world, total), "i32")
+    all_idx[rank], all_d2[rank], all_cnt[rank] = ridx, rd2, rcnt
+    all_idx = yield all_idx
+    all_d2 = yield all_d2
+    all_cnt = yield all_cnt
+    midx, md2, mcnt = engine.merge_rows(all_idx, all_d2, all_cnt)
+    avg, nrm = engine.rows_consumers(pts, cache, queries, midx, mcnt, want_normals)
+    box[queries] = avg  # (every rank patches every repeated query: the array stays the same everywhere)
+    sh["idx"][rows], sh["cnt"][rows] = midx[mine], mcnt[mine]
+    sh["d2"][rows] = engine.cast_like(md2[mine], sh["d2"])
+    sh["avg"][rows] = avg[mine]
+    if want_normals:
+        sh["normals"][rows] = nrm[mine]
+    sh["n_repeated"] = total
+
+
 def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, want_normals: bool = True,
                         **search_kw):
     """``pipeline_steps`` with an index of the rank's own slab instead of a replicated one: rows, mean distances
     and normals of the rank's z interval from ONE search of the slab, then one exchange -- the mean distances
     put together (each rank fills its own rows of a zeroed array: adding the others' zeros is exact), with the
-    number of answers the slabs cannot vouch for riding along.  If there are any, the whole job is repeated on
-    the replicated index: results are exact either way.  Returns what ``pipeline_steps`` returns; rows with
-    ``owned`` < 0 belong to a neighbouring rank."""
+    number of answers the slabs cannot vouch for riding along.  Those are repeated across the ranks
+    (``_repeat_unvouched``); if they are too many for that, the whole job goes to the replicated index: results are
+    exact either way.  Returns what ``pipeline_steps`` returns; rows with ``owned`` < 0 belong to a neighbouring
+    rank."""
     plan = slab_cuts(engine, pts, cache, k, world)
     if plan is None:
         return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, want_normals, **search_kw))
@@ -186,8 +230,11 @@ def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank
                             avg_full=box, **search_kw)
     box[n] = float(sh["n_uncertain"])
     box = yield box
-    if float(box[n]) != 0.0:
+    total = int(float(box[n]))
+    if total > min(SLAB_REPEAT_MAX, max(n // 32, 1)):  # (the halo does not fit this cloud at all)
         return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, want_normals, **search_kw))
+    if total > 0:
+        yield from _repeat_unvouched(engine, pts, cache, k, sh, box, rank, world, total, want_normals)
     kept, stats = engine.sor_from_avg(box, n, std_ratio)
     return sh, kept, stats
 

@@ -397,12 +397,13 @@ class HipEngine:
         return out
 
     # -- one rank of a multi-GPU job with an index of its own slab of the cloud -------------------------------
-    def axis_histogram(self, pts, cache, axis: int, lo: float, hi: float, nbins: int) -> np.ndarray:
+    def axes_histogram(self, pts, cache, lo, hi, nbins: int) -> np.ndarray:
+        """(3, nbins) counts of the points per bin of [lo[a], hi[a]] along every axis a, from one pass."""
         t = self.dev_points(pts, cache)
-        out = np.zeros(nbins, dtype=np.uint32)
-        self._check(self.lib.pc_axis_histogram(self.ctx, _ptr(t), self._dt(t), len(pts), int(axis), float(lo), float(hi),
-                                               int(nbins), out.ctypes.data_as(C.c_void_p), self.stream()),
-                    "pc_axis_histogram")
+        out = np.zeros((3, nbins), dtype=np.uint32)
+        l, h = (C.c_double * 3)(*[float(v) for v in lo]), (C.c_double * 3)(*[float(v) for v in hi])
+        self._check(self.lib.pc_axis_histogram(self.ctx, _ptr(t), self._dt(t), len(pts), -1, l, h, int(nbins),
+                                               out.ctypes.data_as(C.c_void_p), self.stream()), "pc_axis_histogram")
         return out
 
     def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False,
@@ -463,6 +464,7 @@ class HipEngine:
         if want_normals:
             out["normals"] = self.empty((rows, 3), torch.float64)
         n_own, n_unc = C.c_int64(0), C.c_int64(0)
+        unc_rows = self.empty((max(rows, 1),), torch.int32)
         lap("range+outputs")
         if rows > 0:
             self._check(self.lib.pc_knn_fused_compact(self.ctx, g.h, b, e, int(k), float(radius), _ptr(out["idx"]),
@@ -476,11 +478,57 @@ class HipEngine:
             self._check(self.lib.pc_slab_finish(self.ctx, _ptr(t), self._dt(t), None, rows, int(k), float(radius),
                                                 _ptr(out["idx"]), _ptr(out["d2"]), self._dt(out["d2"]), _ptr(out["cnt"]),
                                                 _ptr(out["owned"]), float(own_lo), float(own_hi), open_lo, open_hi,
-                                                _ptr(out.get("avg")), _ptr(avg_full), C.byref(n_own), C.byref(n_unc),
-                                                self.stream()), "pc_slab_finish")
+                                                _ptr(out.get("avg")), _ptr(avg_full), _ptr(unc_rows), C.byref(n_own),
+                                                C.byref(n_unc), self.stream()), "pc_slab_finish")
         lap("finish")
         out["n_own"], out["n_uncertain"] = n_own.value, n_unc.value
+        out["uncertain_rows"] = unc_rows[: n_unc.value].to(torch.int64)  # rows whose answers are to be repeated
+        out["slab_key"] = key
         return out
+
+    def slab_requery(self, pts, cache, slab_key, qidx: torch.Tensor, k: int):
+        """The points ``qidx`` (indices of the whole cloud) as queries against this rank's slab index: rows in
+        indices of the whole cloud, fp64 distances, counts."""
+        t = self.dev_points(pts, cache)
+        gidx, xyz, g = cache[slab_key]
+        m = qidx.numel()
+        idx = torch.full((m, k), -1, dtype=torch.int32, device=self.device)
+        d2 = torch.full((m, k), float("inf"), dtype=torch.float64, device=self.device)
+        cnt = torch.zeros((m,), dtype=torch.int32, device=self.device)
+        if g is None or m == 0:
+            return idx, d2, cnt
+        q = self.empty((m, 3), t.dtype)
+        gather = self.lib.pc_gather_rows_f32 if t.dtype == torch.float32 else self.lib.pc_gather_rows
+        self._check(gather(self.ctx, _ptr(t), _ptr(qidx), m, _ptr(q), self.stream()), "pc_gather_rows")
+        self._check(self.lib.pc_knn(self.ctx, g.h, _ptr(q), self._dt(q), m, int(k), -1.0, _ptr(idx), _ptr(d2), _lib.PC_F64,
+                                    _ptr(cnt), self.stream()), "pc_knn")
+        return idx, d2, cnt
+
+    def merge_rows(self, idx_all: torch.Tensor, d2_all: torch.Tensor, cnt_all: torch.Tensor):
+        world, m, k = idx_all.shape
+        idx = self.empty((m, k), torch.int32)
+        d2 = self.empty((m, k), torch.float64)
+        cnt = self.empty((m,), torch.int32)
+        self._check(self.lib.pc_merge_rows(self.ctx, world, m, k, _ptr(idx_all), _ptr(d2_all), _ptr(cnt_all), _ptr(idx),
+                                           _ptr(d2), _ptr(cnt), self.stream()), "pc_merge_rows")
+        return idx, d2, cnt
+
+    def rows_consumers(self, pts, cache, qidx: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor, want_normals: bool):
+        """Mean neighbour distance (and normal) of the listed points from their finished rows."""
+        t = self.dev_points(pts, cache)
+        m, k = idx.shape
+        avg = self.empty((m,), torch.float64)
+        nrm = self.empty((m, 3), torch.float64) if want_normals else None
+        self._check(self.lib.pc_rows_consumers(self.ctx, _ptr(t), self._dt(t), _ptr(qidx), m, k, _ptr(idx), _ptr(cnt),
+                                               _ptr(avg), _ptr(nrm), self.stream()), "pc_rows_consumers")
+        return avg, nrm
+
+    def zeros(self, shape, kind: str) -> torch.Tensor:
+        return torch.zeros(shape, dtype=torch.int32 if kind == "i32" else torch.float64, device=self.device)
+
+    @staticmethod
+    def cast_like(x: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        return x.to(like.dtype)
 
     def zeros_f64(self, m: int) -> torch.Tensor:
         return torch.zeros((m,), dtype=torch.float64, device=self.device)

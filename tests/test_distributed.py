@@ -195,8 +195,8 @@ def _check_slab_results(pts, res, k, oracle, want_slab):
 @pytest.mark.parametrize("name", ["uniform", "stray", "flat"])
 def test_slab_pipeline_matches_whole_cloud(oracle, name):
     """pipeline_steps_slab with the oracle engine for several pretended worlds: exact rows whether the slabs
-    vouch for every answer ("uniform"), fall back because of one stray point ("stray") or do not pay at all
-    ("flat": a cloud without depth along z)."""
+    vouch for every answer ("uniform"), have the answers of a few stray points repeated across the ranks
+    ("stray") or do not pay at all ("flat": a cloud without depth along z)."""
     from oracle.engine import OracleEngine
     from point_cloud_processing_amd import distributed as PD
 
@@ -205,7 +205,11 @@ def test_slab_pipeline_matches_whole_cloud(oracle, name):
     stats = []
     for world in (1, 2, 4):
         res = PD.run_emulated(lambda r: PD.pipeline_steps_slab(OracleEngine(), pts, k, 2.0, {}, r, world), world)
-        stats.append(_check_slab_results(pts, res, k, oracle, want_slab=name == "uniform" or world == 1))
+        slabbed = PD.slab_cuts(OracleEngine(), pts, {}, k, world) is not None
+        assert slabbed == (name == "uniform" or world == 1 or (name == "stray" and world == 2))
+        stats.append(_check_slab_results(pts, res, k, oracle, want_slab=slabbed))
+        if name == "stray" and world == 2:  # the strays' answers were repeated across the ranks, not the whole job
+            assert all(sh.get("n_repeated", 0) > 0 for sh, _, _ in res)
     if name == "uniform":
         assert stats[0] == stats[1] == stats[2]  # one fixed tree over the whole array: any world, same bits
 
@@ -224,23 +228,29 @@ def test_slab_cuts_partition_and_balance(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["uniform", "stray", "planes"])
+@pytest.mark.parametrize("name", ["uniform", "stray", "planes", "outliers"])
 def test_slab_pipeline_on_the_hip_engine(hip, oracle, name):
     """The same with the HIP engine (slab subsets, their own indexes, pc_slab_finish) for 1, 2, 3 and 8
     pretended ranks on this GPU."""
     from point_cloud_processing_amd import distributed as PD
 
     pts = {"planes": lambda: D.planar_patches(300000, 7, extent=20.0, n_patches=12),
-           "uniform": lambda: D.uniform_cube(400000, 5), "stray": lambda: _slab_clouds()["stray"]}[name]()
-    k = 8 if name == "uniform" else 12
+           "uniform": lambda: D.uniform_cube(400000, 5), "stray": lambda: _slab_clouds()["stray"],
+           # a scan with outliers: a few dozen points far outside the bulk (what the statistical filter is for)
+           "outliers": lambda: np.concatenate([D.uniform_cube(400000, 8), np.random.default_rng(9).random((60, 3)) * 3.0 - 1.0]
+                                              ).astype(np.float32).astype(np.float64)}[name]()
+    k = 8 if name in ("uniform", "outliers") else 12
     stats = []
     for world in (1, 2, 3, 8):
         cache = {}
         res = PD.run_emulated(lambda r: PD.pipeline_steps_slab(hip, pts, k, 2.0, cache, r, world), world)
         plan = PD.slab_cuts(hip, pts, {}, k, world)
         slabbed = "sub_n" in res[0][0]
-        assert slabbed == (plan is not None and (name != "stray" or world == 1))
+        assert slabbed == (plan is not None)
         stats.append(_check_slab_results(pts, res, k, oracle, want_slab=slabbed))
+        if (name == "stray" and world == 2) or (name == "outliers" and world > 1):
+            # the strays' answers were repeated across the ranks, not the whole job
+            assert slabbed and all(sh.get("n_repeated", 0) > 0 for sh, _, _ in res)
     if name == "uniform":
         assert PD.slab_cuts(hip, pts, {}, k, 8) is not None
         assert all(s == stats[0] for s in stats)
