@@ -263,3 +263,74 @@ def test_loader_subsample_gathers_on_the_device(hip):
     out = subsample_point_cloud(pcd, 20000, "a/b.e57")
     assert out._h["points"] is None
     assert np.array_equal(np.asarray(out.points), pts[subsample_indices(50000, 20000, "a/b.e57")])
+
+
+def test_slab_entry_points(hip):
+    """The slab calls through the C ABI on their own: histogram, selection, z range, merge and the consumers
+    of finished rows, each against numpy; bad arguments come back as a status."""
+    import ctypes as C
+    import torch
+    from point_cloud_processing_amd import _lib
+    from point_cloud_processing_amd.hip_engine import _ptr
+    lib, ctx = hip.lib, hip.ctx
+    one, two = C.c_int64(0), C.c_int64(0)
+    lo3, hi3 = (C.c_double * 3)(0, 0, 0), (C.c_double * 3)(1, 1, 1)
+    cnt = (C.c_uint32 * 8)()
+    assert lib.pc_axis_histogram(ctx, None, 0, 5, 2, lo3, hi3, 8, cnt, None) != 0          # null cloud
+    assert lib.pc_axis_histogram(ctx, None, 0, 0, 2, lo3, hi3, 8, cnt, None) == 0          # empty cloud
+    assert lib.pc_axis_histogram(ctx, None, 0, 0, 2, lo3, hi3, 5000, cnt, None) != 0       # too many bins
+    assert lib.pc_select_slab(ctx, None, 0, 5, 2, 0.0, 1.0, None, C.byref(one), None) != 0
+    assert lib.pc_grid_axis_range(ctx, None, 0.0, 1.0, C.byref(one), C.byref(two), None) != 0
+    assert lib.pc_grid_relabel(ctx, None, None, 5, None) != 0
+    assert lib.pc_merge_rows(ctx, 0, 1, 4, None, None, None, None, None, None, None) != 0   # no ranks
+    assert lib.pc_merge_rows(ctx, 2, 0, 4, None, None, None, None, None, None, None) == 0   # no queries
+    assert lib.pc_rows_consumers(ctx, None, 0, None, 3, 4, None, None, None, None, None) != 0
+    assert lib.pc_slab_finish(ctx, None, 0, None, 3, 4, -1.0, None, None, 0, None, None, 0.0, 1.0, 0.0, 1.0, None, None, None,
+                              C.byref(one), C.byref(two), None) != 0
+
+    rng = np.random.default_rng(12)
+    p = rng.random((50000, 3)).astype(np.float32)
+    t = torch.from_numpy(p).to(hip.device)
+    h = hip.axes_histogram(t, {}, [0, 0, 0], [1, 1, 1], 64)
+    want = np.stack([np.bincount(np.clip(np.floor(p[:, a].astype(np.float64) * 64), 0, 63).astype(int), minlength=64) for a in range(3)])
+    assert np.array_equal(h, want)
+    idx = torch.empty(50000, dtype=torch.int32, device=hip.device)
+    m = C.c_int64(0)
+    hip._check(lib.pc_select_slab(ctx, _ptr(t), _lib.PC_F32, 50000, 2, 0.25, 0.5, _ptr(idx), C.byref(m), hip.stream()), "select")
+    assert np.array_equal(idx[: m.value].cpu().numpy(), np.nonzero((p[:, 2] >= 0.25) & (p[:, 2] < 0.5))[0])
+    # z range of a grid: every point with z in [0.25, 0.5] lies inside the range of sorted positions
+    g = hip.grid(t, {}, 16)
+    b, e = C.c_int64(0), C.c_int64(0)
+    hip._check(lib.pc_grid_axis_range(ctx, g.h, 0.25, 0.5, C.byref(b), C.byref(e), hip.stream()), "range")
+    perm = torch.empty(50000, dtype=torch.int32, device=hip.device)
+    hip._check(lib.pc_grid_perm_copy(ctx, g.h, 0, 50000, _ptr(perm), hip.stream()), "perm")
+    inside = np.zeros(50000, dtype=bool)
+    inside[perm[b.value:e.value].cpu().numpy()] = True
+    assert inside[(p[:, 2] >= 0.25) & (p[:, 2] <= 0.5)].all() and 0 < e.value - b.value < 0.4 * 50000
+    # merge: three ranks' rows of 40 queries, k = 6, with shared entries
+    k, nq, world = 6, 40, 3
+    pool_d = np.sort(rng.random((nq, 14)), axis=1)
+    pool_i = np.stack([rng.permutation(1000)[:14] for _ in range(nq)]).astype(np.int32)
+    pool_d[:, 5] = pool_d[:, 4]  # an exact tie: lower index first
+    ia = np.full((world, nq, k), -1, dtype=np.int32)
+    da = np.full((world, nq, k), np.inf)
+    ca = np.zeros((world, nq), dtype=np.int32)
+    for q in range(nq):
+        ent = sorted(zip(pool_d[q], pool_i[q]))
+        for w in range(world):
+            mine = [x for j, x in enumerate(ent) if (j + q) % world == w or j % 4 == 0][: k - (q % 2)]  # overlapping subsets
+            ca[w, q] = len(mine)
+            for s, (d, i) in enumerate(mine):
+                ia[w, q, s], da[w, q, s] = i, d
+    midx, md2, mcnt = hip.merge_rows(*(torch.from_numpy(x).to(hip.device) for x in (ia, da, ca)))
+    for q in range(nq):
+        ent = sorted({(float(da[w, q, s]), int(ia[w, q, s])) for w in range(world) for s in range(ca[w, q])})[:k]
+        assert int(mcnt[q]) == len(ent)
+        assert [(float(d), int(i)) for d, i in zip(md2[q, :len(ent)].cpu(), midx[q, :len(ent)].cpu())] == ent
+    # consumers of finished rows = the fused search's own outputs
+    pts = p.astype(np.float64)
+    ridx, rd2, rcnt, ravg, rnrm = hip.knn_fused(pts, 12, -1.0, {})
+    ql = torch.arange(0, 50000, 7, dtype=torch.int32, device=hip.device)
+    sel = ql.cpu().numpy()
+    avg, nrm = hip.rows_consumers(t, {}, ql, torch.from_numpy(ridx[sel]).to(hip.device), torch.from_numpy(rcnt[sel]).to(hip.device), True)
+    assert np.array_equal(avg.cpu().numpy(), ravg[sel]) and np.array_equal(nrm.cpu().numpy(), rnrm[sel])
