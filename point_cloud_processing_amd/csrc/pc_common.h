@@ -9,6 +9,7 @@
 
 #include "pc_amd.h"
 
+constexpr int EAGER_LEVELS = 4;  // levels of a multi-level index built with it; the rest are made when a search gets that far
 constexpr int MAX_LEVELS = 8;  // resolution levels of one spatial index (pc_grid::coarse chain)
 constexpr int MAX_FINER = 3;   // grids of half the cell edge each, made for the queries too crowded for level 0 (pc_grid::finer chain)
 
@@ -20,6 +21,8 @@ struct PcKnobs {
     bool debug = false;            // PC_AMD_DEBUG: per-pass log on stderr
     double cell_scale = 0.0;       // PC_AMD_CELL_SCALE: scales the automatic cell edge (0: off)
     bool no_halves = false;        // PC_AMD_NO_HALVES
+    int lazy_div = 0;              // PC_AMD_LAZY_DIV: a further level is made while more than n / this many queries are open (0: default)
+    int max_levels = 0;            // PC_AMD_MAX_LEVELS: levels of a multi-level index at most (0: MAX_LEVELS)
     double seed_scale = 0.0;       // PC_AMD_SEED_SCALE: the tile kernel's starting threshold over the certification bound (0: default)
     int uneven_cap = 0;            // PC_AMD_UNEVEN_CAP: candidates an uneven level's tile stages (0: default)
     int tile_waves = 0;            // PC_AMD_TILE_WAVES (0: default)
@@ -188,7 +191,7 @@ struct pc_grid {
     mutable std::vector<uint32_t> full_host;  // host copy of full_tiles (ascending): sub-ranges for query shards
     // the same cloud on a 2x coarser grid (and that one's own `coarse`): built for clouds that
     // fill their box unevenly, used by the exact re-run of queries whose surroundings are sparse
-    pc_grid *coarse = nullptr;
+    mutable pc_grid *coarse = nullptr;  // (the first EAGER_LEVELS levels are built with the index, coarser ones on first need)
     // ... and on a 2x finer grid (and that one's own `finer`): made on first need, for the points
     // whose surroundings are too crowded for every level above; NULL until then
     mutable pc_grid *finer = nullptr;
@@ -210,6 +213,9 @@ inline int64_t pc_index_space(const pc_grid *g) { return g->index_space > 0 ? g-
 int pc_grid_stats(pc_ctx *ctx, const pc_grid *g, hipStream_t st);
 // the same cloud on cells of half the edge (cached in g->finer); *out = NULL if the key range forbids it
 int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out);
+// the next coarser level of a multi-level index (cells of twice the edge; kept in g->coarse); *out = NULL where there
+// is none to make (MAX_LEVELS reached, or the grid is down to four cells an axis)
+int pc_grid_coarser(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out);
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
                    hipStream_t st);
 
