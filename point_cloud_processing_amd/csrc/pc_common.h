@@ -21,6 +21,7 @@ struct PcKnobs {
     bool debug = false;            // PC_AMD_DEBUG: per-pass log on stderr
     double cell_scale = 0.0;       // PC_AMD_CELL_SCALE: scales the automatic cell edge (0: off)
     bool no_halves = false;        // PC_AMD_NO_HALVES
+    int eager_levels = 0;          // PC_AMD_EAGER_LEVELS: levels built with the index (0: EAGER_LEVELS)
     int lazy_div = 0;              // PC_AMD_LAZY_DIV: a further level is made while more than n / this many queries are open (0: default)
     int max_levels = 0;            // PC_AMD_MAX_LEVELS: levels of a multi-level index at most (0: MAX_LEVELS)
     double seed_scale = 0.0;       // PC_AMD_SEED_SCALE: the tile kernel's starting threshold over the certification bound (0: default)

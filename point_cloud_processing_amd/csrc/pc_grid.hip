@@ -76,6 +76,7 @@ PcKnobs pc_read_knobs() {
         if (const char *e = getenv("PC_AMD_SEED_SCALE")) k.seed_scale = atof(e);
         if (const char *e = getenv("PC_AMD_MAX_LEVELS")) k.max_levels = atoi(e);
         if (const char *e = getenv("PC_AMD_LAZY_DIV")) k.lazy_div = atoi(e);
+        if (const char *e = getenv("PC_AMD_EAGER_LEVELS")) k.eager_levels = atoi(e);
         k.uneven_cap = (int)num("PC_AMD_UNEVEN_CAP", 0);
         k.tile_waves = (int)num("PC_AMD_TILE_WAVES", 0);
         if (const char *e = getenv("PC_AMD_TILE")) {
@@ -1060,7 +1061,8 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         // clouds never look at levels 5 to 8, and sorting all points four more times was a fifth to a third of
         // their build: 2 M sphere 1.37 -> 1.0 ms, LiDAR frame 0.95 -> 0.73 ms, 13 M voxels of planes + clutter
         // 7.6 -> 5.4 ms, with the searches as fast or faster.)
-        const int max_lv = ctx->knobs.max_levels > 0 ? std::min(ctx->knobs.max_levels, MAX_LEVELS) : EAGER_LEVELS;
+        const int eager = ctx->knobs.eager_levels >= 2 ? std::min(ctx->knobs.eager_levels, MAX_LEVELS) : EAGER_LEVELS;
+        const int max_lv = ctx->knobs.max_levels > 0 ? std::min(ctx->knobs.max_levels, MAX_LEVELS) : eager;
         for (int lv = 1; lv < max_lv; lv++) {
             if (std::max(fine->gp.dim[0], std::max(fine->gp.dim[1], fine->gp.dim[2])) <= 4) break;
             pc_grid *c = nullptr;

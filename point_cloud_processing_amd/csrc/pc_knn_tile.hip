@@ -613,7 +613,8 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                 // and 136 k after level 7.  A further level is made while an eighth of the points is open -- measured
                 // at an eighth / 16th / 32nd: clusters 4.4 / 5.6 / 5.8 ms, LiDAR frame 1.13 / 1.08 / 1.46 ms, 4 M points
                 // of planes + clutter 14.2 / 15.3 / 15.4 ms (28.9 ms with four levels and no more).)
-                if (open >= std::max<int64_t>(std::max<int64_t>(2048, A.nq / 200), l->n / (knobs.lazy_div > 0 ? knobs.lazy_div : 8))) {
+                if (open >= std::max<int64_t>(std::max<int64_t>(2048, A.nq / 200),
+                                              nlv >= EAGER_LEVELS ? l->n / (knobs.lazy_div > 0 ? knobs.lazy_div : 8) : 0)) {
                     const pc_grid *more = nullptr;
                     PC_TRY(pc_grid_coarser(ctx, lv[i], st, &more));
                     if (more) lv[nlv++] = more;
