@@ -220,6 +220,13 @@ int pc_grid_coarser(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
                    hipStream_t st);
 
+// pc_knn_tile.hip
+// The tile of the cooperative kNN kernel for a cloud that fills its box with `occ` points per cell on a grid of `dim`
+// cells: the fullest shape whose expected population (+ 1.5 sigma) fits the workgroup's lanes; *waves = waves per
+// workgroup, *pop = expected queries per tile.  Pure arithmetic: the grid build uses it to pick, among cell edges
+// within a few per cent of each other, the one whose tiles divide the grid best.
+void pc_dense_tile_shape(const pc_ctx *ctx, double occ, const int32_t dim[3], int tile[3], int *waves, double *pop);
+
 // pc_sort.hip
 // device address of this GPU's copy of the static scratch array behind pc_sor_select_static (once per device)
 int pc_static_scratch_init(int device);

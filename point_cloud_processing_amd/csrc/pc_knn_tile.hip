@@ -210,13 +210,59 @@ __global__ __launch_bounds__(256) void k_open_range(const REC *__restrict__ rec,
     qub[id] = INFINITY;
 }
 
+}  // namespace
+
+void pc_dense_tile_shape(const pc_ctx *ctx, double occ, const int32_t dim[3], int best[3], int *waves_out, double *pop_out) {
+    int waves = MAX_TILE_WAVES;  // measured at 10 M, k = 16: 4 waves 2.78 ms, 2 waves 3.27 ms (LDS-bound occupancy)
+    if (const int e = ctx->knobs.tile_waves) waves = std::min(MAX_TILE_WAVES, std::max(1, e));
+    best[0] = best[1] = best[2] = 1;
+    double best_pop = -1.0, best_block = 0.0;
+    for (int tz = 1; tz <= 6; tz++)
+        for (int ty = 1; ty <= 6; ty++)
+            for (int tx = 1; tx + 2 <= MAX_NX; tx++) {
+                if ((ty + 2) * (tz + 2) > MAX_ROWS) continue;
+                if (tx > std::max(1, (int)dim[0]) || ty > std::max(1, (int)dim[1]) || tz > std::max(1, (int)dim[2])) continue;
+                const double pop = occ * tx * ty * tz, block = (double)(tx + 2) * (ty + 2) * (tz + 2);
+                const double cand = occ * block;
+                if (pop + 1.5 * sqrt(pop) > (double)(PC_WAVE * waves) && !(tx == 1 && ty == 1 && tz == 1)) continue;
+                if (cand + 6.0 * sqrt(cand) + 8.0 > (double)CAND_CAP_MAX && !(tx == 1 && ty == 1 && tz == 1)) continue;
+                if (pop > best_pop * 1.0001 || (pop > best_pop * 0.9999 && block < best_block)) {
+                    best_pop = pop;
+                    best_block = block;
+                    best[0] = tx;
+                    best[1] = ty;
+                    best[2] = tz;
+                }
+            }
+    {   // tuning knob: "tx,ty,tz"
+        const int *v = ctx->knobs.tile;
+        if (v[0] >= 1 && v[0] + 2 <= MAX_NX && v[1] >= 1 && v[2] >= 1 && (v[1] + 2) * (v[2] + 2) <= MAX_ROWS) {
+            for (int a = 0; a < 3; a++) best[a] = std::min(v[a], std::max(1, (int)dim[a]));
+            best_pop = occ * best[0] * best[1] * best[2];
+        }
+    }
+    // no more waves than the expected population needs
+    waves = std::min(waves, std::max(1, (int)ceil((best_pop + 1.5 * sqrt(std::max(best_pop, 0.0))) / PC_WAVE)));
+    if (waves_out) *waves_out = waves;
+    if (pop_out) *pop_out = best_pop;
+}
+
+namespace {
+
 // chooses g->tile / g->tile_cap (once per grid)
 // listed: how many queries the level's pass is to answer, where the caller knows (coarser levels of an
 // uneven index, whose tiles are settled when the level is first searched); 0: unknown.
 int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 0) {
     if (g->tile[0] > 0) return PC_OK;
-    const double occ = (double)g->n / (double)std::max<int64_t>(1, g->ncell);
+    double occ = (double)g->n / (double)std::max<int64_t>(1, g->ncell);
     const bool dense = !g->uneven;
+    if (dense) {
+        // points per cell where the cloud is (the last layer of cells of an axis is only partly inside the box): what
+        // a tile's population follows -- n / ncell runs a few per cent low and lets tiles overflow their lanes
+        double box = 1.0;
+        for (int a = 0; a < 3; a++) box *= std::max(g->bb_max[a] - g->bb_min[a], g->gp.cell);
+        occ = std::max(occ, (double)g->n * g->gp.cell * g->gp.cell * g->gp.cell / box);
+    }
     int best[3] = {1, 1, 1};
     double expect;
     int waves = 1;
@@ -225,37 +271,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
         // bigger tile pays less halo per query and less LDS per wave.  Take the fullest shape whose
         // expected population (plus 1.5 sigma) still fits the workgroup's lanes; among equals the one
         // with the smallest block.
-        waves = MAX_TILE_WAVES;  // measured at 10 M, k = 16: 4 waves 2.78 ms, 2 waves 3.27 ms (LDS-bound occupancy)
-        if (const int e = ctx->knobs.tile_waves) waves = std::min(MAX_TILE_WAVES, std::max(1, e));
-        double best_pop = -1.0, best_block = 0.0;
-        for (int tz = 1; tz <= 6; tz++)
-            for (int ty = 1; ty <= 6; ty++)
-                for (int tx = 1; tx + 2 <= MAX_NX; tx++) {
-                    if ((ty + 2) * (tz + 2) > MAX_ROWS) continue;
-                    if (tx > std::max(1, (int)g->gp.dim[0]) || ty > std::max(1, (int)g->gp.dim[1]) ||
-                        tz > std::max(1, (int)g->gp.dim[2]))
-                        continue;
-                    const double pop = occ * tx * ty * tz, block = (double)(tx + 2) * (ty + 2) * (tz + 2);
-                    const double cand = occ * block;
-                    if (pop + 1.5 * sqrt(pop) > (double)(PC_WAVE * waves) && !(tx == 1 && ty == 1 && tz == 1)) continue;
-                    if (cand + 6.0 * sqrt(cand) + 8.0 > (double)CAND_CAP_MAX && !(tx == 1 && ty == 1 && tz == 1)) continue;
-                    if (pop > best_pop * 1.0001 || (pop > best_pop * 0.9999 && block < best_block)) {
-                        best_pop = pop;
-                        best_block = block;
-                        best[0] = tx;
-                        best[1] = ty;
-                        best[2] = tz;
-                    }
-                }
-        {   // tuning knob: "tx,ty,tz"
-            const int *v = ctx->knobs.tile;
-            if (v[0] >= 1 && v[0] + 2 <= MAX_NX && v[1] >= 1 && v[2] >= 1 && (v[1] + 2) * (v[2] + 2) <= MAX_ROWS) {
-                for (int a = 0; a < 3; a++) best[a] = std::min(v[a], std::max(1, (int)g->gp.dim[a]));
-                best_pop = occ * best[0] * best[1] * best[2];
-            }
-        }
-        // no more waves than the expected population needs
-        waves = std::min(waves, std::max(1, (int)ceil((best_pop + 1.5 * sqrt(std::max(best_pop, 0.0))) / PC_WAVE)));
+        pc_dense_tile_shape(ctx, occ, g->gp.dim, best, &waves, nullptr);
         expect = occ * (best[0] + 2) * (best[1] + 2) * (best[2] + 2);
         expect += 6.0 * sqrt(expect) + 8.0;  // Poisson mean + 6 sigma
     } else {

@@ -21,7 +21,7 @@ for dd in ("fetch", "write"):
     tr[dd] = sum(v) / len(v)
 t = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (one pass each) over `python3 bench.py --steps 2 --warmup 1 "
                "--no-cpu --no-pipeline`, MI355X; per-launch means",
-     "kernel": "k_tile_scan<Rec32,18,M_KNN> (10 M points, k=16; 4-wave workgroups, tile 5x3x2 cells)",
+     "kernel": "k_tile_scan<Rec32,18,M_KNN> (10 M points, k=16; 4-wave workgroups, tile 4x4x2 cells of a 112^3 grid)",
      "points": 10_000_000, "k": 16,
      "note": "FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64-byte requests as 32 bytes, hence x2 "
              "(MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is exact",
