@@ -220,7 +220,7 @@ int pc_gather_rows_f32(pc_ctx *ctx, const float *src_dev, const int32_t *idx_dev
                        void *stream);
 
 /* ---- slabs: one rank of a multi-GPU job indexes only its part of the cloud --------------------------------
- * The reference has no distribution of any kind; these four calls serve the query sharding of
+ * The reference has no distribution of any kind; the calls of this section serve the query sharding of
  * remove_statistical_outlier / estimate_normals (filtering_adapter.py:91, pointcloud_preprocess.py:109-114)
  * where sorting all n points on every rank would bound the speed-up.  A rank takes the points whose coordinate
  * along `axis` lies in [own_lo - halo, own_hi + halo) (pc_select_slab + pc_gather_rows*), indexes that subset
