@@ -235,7 +235,7 @@ def test_slab_cuts_partition_and_balance(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["uniform", "stray", "planes", "outliers"])
+@pytest.mark.parametrize("name", ["uniform", "uniform_fp64", "stray", "planes", "outliers"])
 def test_slab_pipeline_on_the_hip_engine(hip, oracle, name):
     """The same with the HIP engine (slab subsets, their own indexes, pc_slab_finish) for 1, 2, 3 and 8
     pretended ranks on this GPU."""
@@ -243,10 +243,11 @@ def test_slab_pipeline_on_the_hip_engine(hip, oracle, name):
 
     pts = {"planes": lambda: D.planar_patches(300000, 7, extent=20.0, n_patches=12),
            "uniform": lambda: D.uniform_cube(400000, 5), "stray": lambda: _slab_clouds()["stray"],
+           "uniform_fp64": lambda: D.uniform_cube(300000, 15, fp32=False) * 3.0 + 1000.0,  # (fp64 records)
            # a scan with outliers: a few dozen points far outside the bulk (what the statistical filter is for)
            "outliers": lambda: np.concatenate([D.uniform_cube(400000, 8), np.random.default_rng(9).random((60, 3)) * 3.0 - 1.0]
                                               ).astype(np.float32).astype(np.float64)}[name]()
-    k = 8 if name in ("uniform", "outliers") else 12
+    k = 8 if name in ("uniform", "uniform_fp64", "outliers") else 12
     stats = []
     for world in (1, 2, 3, 8):
         cache = {}
