@@ -143,3 +143,57 @@ def test_mixed_first_pass_agrees(hip, oracle, monkeypatch, k):
         assert np.array_equal(sh["cnt"], rcnt[owned])
         seen[owned] += 1
     assert (seen == 1).all()
+
+
+def test_config4_at_full_size(hip):
+    """BASELINE configs[3] at its full size: 100 M points of planes + clutter -> voxel 0.05 m -> 66 M voxels ->
+    kNN(32) rows + mean distances.  Too big for the CPU oracle: checked through properties that do not depend on
+    size (every row ascending and led by the query itself, every point a query once), against a brute-force
+    search of sampled rows (torch on the device, fp64, the reference's operation order) and against the
+    multi-GPU slab path (one rank of eight: the same bits for the same queries)."""
+    import ctypes as C
+    import torch
+    from point_cloud_processing_amd import _lib, distributed as PD
+    from point_cloud_processing_amd.hip_engine import _ptr
+
+    N, K = 100_000_000, 32
+    xyz = torch.cat([torch.from_numpy(D.planar_patches(10_000_000, 5 + c).astype(np.float32)).to(hip.device) for c in range(N // 10_000_000)])
+    out = torch.empty((N, 3), dtype=torch.float64, device=hip.device)
+    m = C.c_int64(0)
+    hip._check(hip.lib.pc_voxel_downsample(hip.ctx, _ptr(xyz), _lib.PC_F32, None, None, N, 0.05, _ptr(out), None, None, None, None,
+                                           C.byref(m), hip.stream()), "voxel")
+    del xyz
+    mm = m.value
+    assert 60_000_000 < mm < 70_000_000
+    cent = out[:mm]
+    cache = {"xyz": cent}
+    sh = hip.shard_search(cent, cache, K, -1.0, 0, mm, want_rows=True, want_avg=True, d2_dtype=torch.float32)
+    idx, d2, owned = sh["idx"], sh["d2"], sh["owned"]
+    assert bool((sh["cnt"] == K).all())
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all()) and bool((d2[:, 0] == 0).all()) and bool((idx[:, 0] == owned).all())
+    seen = torch.zeros(mm, dtype=torch.int32, device=hip.device)
+    seen[owned.long()] += 1
+    assert bool((seen == 1).all())
+    row_of = torch.empty(mm, dtype=torch.int64, device=hip.device)
+    row_of[owned.long()] = torch.arange(mm, device=hip.device)
+    rng = np.random.default_rng(0)
+    for q in rng.integers(0, mm, 24):
+        dx, dy, dz = cent[:, 0] - cent[q, 0], cent[:, 1] - cent[q, 1], cent[:, 2] - cent[q, 2]
+        dd = dx * dx
+        dd = dd + dy * dy
+        dd = dd + dz * dz
+        v, _ = torch.topk(dd, K + 8, largest=False, sorted=True)
+        cand = torch.nonzero(dd <= v[-1]).flatten().cpu().numpy()
+        want = cand[np.lexsort((cand, dd[cand].cpu().numpy()))[:K]]
+        r = int(row_of[q])
+        assert np.array_equal(want, idx[r].cpu().numpy()) and np.array_equal(dd[want].float().cpu().numpy(), d2[r].cpu().numpy())
+        assert abs(float(sh["avg"][r]) - float(torch.sqrt(dd[want]).sum() / K)) < 1e-12
+    # one rank of eight through the slab path: its own index of its own part of the cloud, the same rows
+    cuts, halo = PD.slab_cuts(hip, cent, cache, K, 8)
+    sl = hip.slab_search(cent, cache, K, -1.0, cuts[3], cuts[4], halo, want_avg=True, d2_dtype=torch.float32)
+    assert sl["n_uncertain"] == 0 and sl["sub_n"] < 0.2 * mm
+    own = sl["owned"] >= 0
+    rows = row_of[sl["owned"][own].long()]
+    assert int(own.sum()) == sl["n_own"] and abs(sl["n_own"] - mm / 8) < 0.02 * mm
+    assert bool((sl["idx"][own] == idx[rows]).all()) and bool((sl["d2"][own] == d2[rows]).all())
+    assert bool((sl["avg"][own] == sh["avg"][rows]).all())
