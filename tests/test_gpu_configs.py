@@ -197,3 +197,33 @@ def test_config4_at_full_size(hip):
     assert int(own.sum()) == sl["n_own"] and abs(sl["n_own"] - mm / 8) < 0.02 * mm
     assert bool((sl["idx"][own] == idx[rows]).all()) and bool((sl["d2"][own] == d2[rows]).all())
     assert bool((sl["avg"][own] == sh["avg"][rows]).all())
+
+
+def test_config3_stream_of_frames(hip, oracle):
+    """BASELINE configs[2] as a stream: distinct 120 k-point LiDAR frames one after the other through the same
+    engine (voxel 0.1 m, normals with 30 neighbours, buffers of the previous frame reused by the pool), every
+    frame against the oracle."""
+    for f in range(8):
+        p = D.lidar_frame(40 + f)
+        vp, _, _ = hip.voxel_downsample(p, None, None, 0.1, {})
+        rvp, _, _ = oracle.voxel_downsample(p, 0.1)
+        assert np.array_equal(vp, rvp)
+        n = hip.normals(vp, 30, -1.0, None, {})
+        assert np.abs(n - oracle.normals(vp, 30)).max() < 1e-6
+
+
+def test_config5_at_full_size(hip, oracle):
+    """BASELINE configs[4] at its full size: 2 M source points against a 2 M-point target, k = 1, under scripted
+    rigid perturbations (three of the thirty iterations: the oracle needs a second for each)."""
+    target = D.torus(2_000_000, 6)
+    rng = np.random.default_rng(7)
+    source = target[rng.permutation(len(target))] + rng.standard_normal((len(target), 3)) * 0.001
+    cache = {}
+    g = oracle.Grid(target, target=2.0)
+    for it in (0, 9, 29):
+        a = 0.05 / (it + 1)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        q = (source @ R.T + np.array([0.01, -0.005, 0.002]) / (it + 1)).astype(np.float32).astype(np.float64)
+        idx, d2, cnt = hip.knn(target, q, 1, -1.0, cache)
+        ridx, rd2, rcnt = g.knn(q, 1)
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and (cnt == 1).all()
