@@ -110,7 +110,7 @@ class Harness:
         if args.rehearse:  # every rank on GPU 0, gloo's collectives on device tensors: the multi-rank code path on a one-GPU box
             import faulthandler
 
-            faulthandler.dump_traceback_later(60, exit=True)  # (a rehearsal that hangs says where)
+            faulthandler.dump_traceback_later(900, exit=True)  # (a rehearsal that hangs says where, and ends)
             self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         if self.world > 1 and args.rehearse:
