@@ -1,5 +1,5 @@
 """Per-rank time of the slab path against the replicated index, for pretended worlds on ONE GPU (development aid
-and the source of the scaling arithmetic in DESIGN.md): every rank's work is run in turn and timed on its own.
+and the source of the per-rank scaling figures): every rank's work is run in turn and timed on its own.
 Usage: python scratch/bench_slab.py headline|c4 [points]"""
 import sys, os, time, json, ctypes as C
 import numpy as np, torch

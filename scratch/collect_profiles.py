@@ -1,4 +1,4 @@
-"""Copies the summaries of gpurun_out/prof (scratch/profile_round.sh) into profiles/ under this round's names."""
+"""Copies the summaries of gpurun_out/prof (scratch/profile_round.sh) into profiles/ under the given prefix."""
 import collections, csv, glob, json, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 P = "gpurun_out/prof"
