@@ -9,8 +9,8 @@ The statistical outlier filter has one real exchange step, its global mean and s
 deviation: every rank fills the per-chunk partial sums of its own slice into a zeroed array, the
 arrays are added elementwise (RCCL all-reduce over xGMI when the backend is "nccl"; adding the
 other ranks' zeros is exact) and every rank finishes the same array with the same fixed tree, so
-the statistics carry the same bits for 1, 2, 4 or 8 ranks.  The kept mask is exchanged the same
-way (one bit per point: the ranks' bits are disjoint, so the sum is the union).  Nothing else crosses GPUs, and nothing visits the host but a few scalars.
+the statistics carry the same bits for 1, 2, 4 or 8 ranks.  The outcome is exchanged the same
+way (one bit per point, set for the points a rank removes: the ranks' bits are disjoint, so the sum is the union).  Nothing else crosses GPUs, and nothing visits the host but a few scalars.
 
 Each algorithm is written once, as a generator that yields the arrays it wants summed over the
 ranks: ``run`` drives it with ``dist.all_reduce``; ``run_emulated`` drives the generators of all
