@@ -39,3 +39,38 @@ def test_hip_matches_golden(hip, path):
     fi, fd, fc, fa, fn = hip.knn_fused(p, 16, -1.0, {})
     assert np.array_equal(fi, g["idx_k16"]) and np.array_equal(fd, g["d2_k16"])
     assert angle_up_to_sign(fn, g["normals_k16"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("shape", ["sphere", "planes", "uniform"])
+def test_hip_against_scipy_and_eigh_at_scale(hip, shape):
+    """A third-party chain that shares no code with the library or its oracle, at a size the committed vectors do
+    not reach: neighbours from scipy's cKDTree, covariance in numpy, smallest eigenvector from numpy.linalg.eigh,
+    statistical filter from numpy -- against the fused search of the HIP engine on 300 k points."""
+    from scipy.spatial import cKDTree
+    import datasets as D
+
+    p = {"sphere": lambda: D.bumpy_sphere(300_000, 21), "planes": lambda: D.planar_patches(300_000, 22, extent=30.0, n_patches=10),
+         "uniform": lambda: D.uniform_cube(300_000, 23)}[shape]()
+    k = 16
+    idx, d2, cnt, avg, nrm = hip.knn_fused(p, k, -1.0, {})
+    dist, nb = cKDTree(p).query(p, k=k, workers=-1)
+    # neighbour sets: equal wherever the k-th and (k+1)-th distances differ (scipy orders ties its own way)
+    same = np.sort(idx, axis=1) == np.sort(nb, axis=1)
+    assert same.all(axis=1).mean() > 0.9999
+    rows = same.all(axis=1)
+    np.testing.assert_allclose(np.sqrt(d2[rows]), dist[rows], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(avg[rows], dist[rows].sum(1) / k, rtol=1e-12)
+    q = p[nb]                                                   # (n, k, 3)
+    c = q - q.mean(axis=1, keepdims=True)
+    cov = np.einsum("nki,nkj->nij", c, c) / k
+    w, v = np.linalg.eigh(cov)
+    want = v[:, :, 0]
+    well = rows & ((w[:, 1] - w[:, 0]) > 1e-3 * w[:, 2])        # (a separated smallest eigenvalue: a defined direction)
+    assert well.mean() > (0.5 if shape == "uniform" else 0.9)
+    assert angle_up_to_sign(nrm[well], want[well]).max() < 1e-6
+    # statistical filter (mean + 2 sigma of the mean distances, Bessel's correction, both comparisons strict)
+    a = dist.sum(1) / k
+    thr = a.mean() + 2.0 * a.std(ddof=1)
+    kept = np.nonzero((a > 0) & (a < thr))[0]
+    got = np.asarray(hip.sor(p, k, 2.0, {}))
+    assert len(np.setxor1d(kept, got)) <= 2                     # (a point within rounding of the threshold may flip)
