@@ -74,3 +74,21 @@ def test_hip_against_scipy_and_eigh_at_scale(hip, shape):
     kept = np.nonzero((a > 0) & (a < thr))[0]
     got = np.asarray(hip.sor(p, k, 2.0, {}))
     assert len(np.setxor1d(kept, got)) <= 2                     # (a point within rounding of the threshold may flip)
+
+
+def test_voxel_against_numpy_at_scale(hip):
+    """voxel_down_sample on a million points against plain numpy: indices by floor((p - (min - vs / 2)) / vs),
+    per-voxel sums in point order (bincount adds in that order), centroids = sums / counts, voxels in ascending
+    (iz, iy, ix) order: bit for bit."""
+    import datasets as D
+
+    p = D.planar_patches(1_000_000, 31, extent=40.0, n_patches=15)
+    vs = 0.07
+    got, _, _ = hip.voxel_downsample(p, None, None, vs, {})
+    vmin = p.min(axis=0) - 0.5 * vs
+    ijk = np.floor((p - vmin) / vs).astype(np.int64)
+    dims = ijk.max(axis=0) + 1
+    key = (ijk[:, 2] * dims[1] + ijk[:, 1]) * dims[0] + ijk[:, 0]
+    _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    want = np.stack([np.bincount(inv, weights=p[:, a]) / cnt for a in range(3)], axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
