@@ -92,3 +92,20 @@ def test_voxel_against_numpy_at_scale(hip):
     _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
     want = np.stack([np.bincount(inv, weights=p[:, a]) / cnt for a in range(3)], axis=1)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_radius_counts_and_nn_distance_against_scipy_at_scale(hip):
+    """remove_radius_outlier's counts and compute_nearest_neighbor_distance on 300 k points against scipy."""
+    from scipy.spatial import cKDTree
+    import datasets as D
+
+    p = D.bumpy_sphere(300_000, 41)
+    tree = cKDTree(p)
+    dist, _ = tree.query(p, k=2, workers=-1)
+    np.testing.assert_allclose(hip.nn_distance(p, {}), dist[:, 1], rtol=1e-12)
+    r = 5.0 * float(np.median(dist[:, 1]))
+    want = tree.query_ball_point(p, r, return_length=True, workers=-1)
+    got = hip.radius_count(p, r, {})
+    assert (got != want).mean() < 1e-5  # (a neighbour within rounding of the radius may count on one side only)
+    kept = np.asarray(hip.radius_outlier(p, 4, r, {}))
+    assert len(np.setxor1d(kept, np.nonzero(want > 4)[0])) <= 2
