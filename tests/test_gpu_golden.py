@@ -53,7 +53,7 @@ def test_hip_against_scipy_and_eigh_at_scale(hip, shape):
          "uniform": lambda: D.uniform_cube(300_000, 23)}[shape]()
     k = 16
     idx, d2, cnt, avg, nrm = hip.knn_fused(p, k, -1.0, {})
-    dist, nb = cKDTree(p).query(p, k=k, workers=-1)
+    dist, nb = cKDTree(p).query(p, k=k, workers=16)
     # neighbour sets: equal wherever the k-th and (k+1)-th distances differ (scipy orders ties its own way)
     same = np.sort(idx, axis=1) == np.sort(nb, axis=1)
     assert same.all(axis=1).mean() > 0.9999
@@ -101,10 +101,10 @@ def test_radius_counts_and_nn_distance_against_scipy_at_scale(hip):
 
     p = D.bumpy_sphere(300_000, 41)
     tree = cKDTree(p)
-    dist, _ = tree.query(p, k=2, workers=-1)
+    dist, _ = tree.query(p, k=2, workers=16)
     np.testing.assert_allclose(hip.nn_distance(p, {}), dist[:, 1], rtol=1e-12)
     r = 5.0 * float(np.median(dist[:, 1]))
-    want = tree.query_ball_point(p, r, return_length=True, workers=-1)
+    want = tree.query_ball_point(p, r, return_length=True, workers=16)
     got = hip.radius_count(p, r, {})
     assert (got != want).mean() < 1e-5  # (a neighbour within rounding of the radius may count on one side only)
     kept = np.asarray(hip.radius_outlier(p, 4, r, {}))
