@@ -27,6 +27,7 @@ def _cloud():
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (gloo otherwise looks the host name up, which may not resolve)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle.engine import OracleEngine
@@ -104,6 +105,7 @@ def _hip_worker(rank, world, port, out_dir, backend):
     one GPU; RCCL itself wants a GPU per rank, so the collective here is gloo's, on DEVICE tensors)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # (gloo otherwise looks the host name up, which may not resolve)
     dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from point_cloud_processing_amd import distributed as PD
