@@ -227,3 +227,12 @@ def test_config5_at_full_size(hip, oracle):
         idx, d2, cnt = hip.knn(target, q, 1, -1.0, cache)
         ridx, rd2, rcnt = g.knn(q, 1)
         assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and (cnt == 1).all()
+
+
+def test_level_made_on_demand(hip, oracle):
+    """4 M points of planes + clutter, k = 32: more than an eighth of the cloud is still open after the four
+    levels built with the index, so the search makes a fifth one itself; rows against the oracle."""
+    p = D.planar_patches(4_000_000, 7)
+    idx, d2, cnt = hip.knn(p, None, 32, -1.0, {})
+    ridx, rd2, rcnt = oracle.Grid(p).knn_self(32)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2) and np.array_equal(cnt, rcnt)
