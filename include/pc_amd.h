@@ -175,12 +175,13 @@ int pc_sor_sqsum(pc_ctx *ctx, const double *avg_dev, int64_t n, double mean, dou
 int pc_sor_select(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshold, uint8_t *out_mask_dev,
                   int32_t *out_kept_dev, int64_t *n_kept, void *stream);
 
-/* pc_sor_select for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
- * pc_sor_select, but the flag bytes and block counts live in a static device array of
- * PC_SOR_SELECT_STATIC_MAX_N + 8 KiB bytes that every GPU the library runs on holds until the process ends:
- * the call performs no hipMalloc / hipFree.  n > PC_SOR_SELECT_STATIC_MAX_N is rejected with PC_BAD_ARG.
- * All calls on one GPU share that array (whatever their context): calls that overlap on one GPU race. */
+/* pc_sor_select for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc).
+ * No counterpart in the reference.  Same arguments and results as pc_sor_select, but the flag bytes and block
+ * counts live in a static device array of PC_SOR_SELECT_STATIC_MAX_N + 8 KiB bytes that every GPU the library
+ * runs on holds until the process ends: the call performs no hipMalloc / hipFree.  Like pc_sor_select it
+ * synchronises the stream to return *n_kept, so it is not for use inside a HIP graph capture.
+ * n > PC_SOR_SELECT_STATIC_MAX_N is rejected with PC_BAD_ARG.  All calls on one GPU share that array
+ * (whatever their context) and take turns under a per-device mutex. */
 #define PC_SOR_SELECT_STATIC_MAX_N (4 * 1024 * 1024)
 int pc_sor_select_static(pc_ctx *ctx, const double *avg_dev, int64_t n, double threshold, uint8_t *out_mask_dev,
                          int32_t *out_kept_dev, int64_t *n_kept, void *stream);

@@ -63,18 +63,10 @@ def _estimate_nn_median(pcd: PointCloud, sample: int = 20000) -> float:
 
 
 def _random_subset(n: int, size: int) -> np.ndarray:
-    """``size`` distinct indices below ``n``, uniformly at random, from NumPy's global generator like the
-    reference's ``np.random.choice(n, size, replace=False)`` (:43) -- drawn by rejecting repeats, which costs
-    O(size) where ``choice`` shuffles all ``n`` indices (7 ms of a 1 M-point filter call).  The subset comes
-    back in ascending order: its only use is a median over the subset, which no order changes."""
-    if n < 4 * size:  # (rejection pays only while most draws are new)
-        return np.random.choice(n, size, replace=False)
-    got = np.unique(np.random.randint(0, n, size=size))
-    while len(got) < size:  # (repeats are rare: size^2 / 2n of them)
-        got = np.union1d(got, np.random.randint(0, n, size=2 * (size - len(got)) + 16))
-    if len(got) > size:  # the surplus leaves at random, so that every subset stays equally likely
-        got = np.delete(got, np.random.choice(len(got), len(got) - size, replace=False))
-    return got
+    """``size`` distinct indices below ``n`` from NumPy's global generator, drawn with the reference's own call
+    (``np.random.choice(n, size, replace=False)``, :43): a caller that seeds ``np.random`` gets the reference's
+    subset, hence its median spacing and the radius derived from it."""
+    return np.random.choice(n, size, replace=False)
 
 
 class _Attempt:

@@ -327,8 +327,8 @@ int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_
 // ---- pc_sor_select_static: the ordered select of the statistical filter without any allocation ---------
 // Same kernels as pc_sor_select / pc_compact_flags; the flag bytes and the per-block counts live in a
 // file-scope device array instead of pooled blocks.  Every GPU holds its own copy of the array (at its own
-// address, looked up once per device in pc_static_scratch_init) until the process ends.  Calls share it:
-// two calls that overlap on one GPU race.
+// address, looked up once per device in pc_static_scratch_init) until the process ends.  Calls on one GPU share
+// it, whatever their context: they take turns under a per-device mutex held until the call's stream has drained.
 namespace {
 
 constexpr int64_t STATIC_MAX_N = PC_SOR_SELECT_STATIC_MAX_N;
@@ -342,6 +342,7 @@ static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
 constexpr int STATIC_MAX_DEVICES = 64;
 void *g_scratch_ptr[STATIC_MAX_DEVICES];  // device address of `scratch` on each GPU (NULL: not looked up)
 std::mutex g_scratch_mu;
+std::mutex g_scratch_busy[STATIC_MAX_DEVICES];  // held from a call's first write to the array until its stream has drained
 
 __global__ __launch_bounds__(256) void k_threshold_flags(const double *__restrict__ avg, int64_t n, double thr,
                                                           uint8_t *__restrict__ flags) {
@@ -381,6 +382,7 @@ extern "C" int pc_sor_select_static(pc_ctx *ctx, const double *avg_dev, int64_t 
         base = reinterpret_cast<unsigned char *>(g_scratch_ptr[ctx->device]);
     }
     if (!base) return pc_fail(ctx, PC_HIP_ERROR, "pc_sor_select_static: no static scratch on this device");
+    std::lock_guard<std::mutex> busy(g_scratch_busy[ctx->device]);  // (released after the synchronise below)
     uint8_t *flags = out_mask_dev ? out_mask_dev : base;
     uint32_t *c = reinterpret_cast<uint32_t *>(base + STATIC_MAX_N);
     const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;

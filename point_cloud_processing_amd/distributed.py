@@ -183,7 +183,7 @@ def _repeat_unvouched(engine, pts, cache: dict, k: int, sh: dict, box, rank: int
     such queries together, EVERY rank answers all of them against its own slab, the rows travel and are merged
     (the slabs cover the cloud, so the k nearest of the union of the ranks' k nearest are the true neighbours).
     Every exchange is a sum of arrays in which each rank fills its own part of zeros.  Patches the rank's rows in
-    ``sh`` and the mean distances in ``box`` (on every rank alike)."""
+    ``sh`` and the mean distances in ``box`` (on every rank alike; ``None``: rows only)."""
     counts = engine.zeros((world,), "f64")
     counts[rank] = float(sh["n_uncertain"])
     counts = yield counts
@@ -202,10 +202,12 @@ def _repeat_unvouched(engine, pts, cache: dict, k: int, sh: dict, box, rank: int
     all_cnt = yield all_cnt
     midx, md2, mcnt = engine.merge_rows(all_idx, all_d2, all_cnt)
     avg, nrm = engine.rows_consumers(pts, cache, queries, midx, mcnt, want_normals)
-    box[queries] = avg  # (every rank patches every repeated query: the array stays the same everywhere)
+    if box is not None:
+        box[queries] = avg  # (every rank patches every repeated query: the array stays the same everywhere)
     sh["idx"][rows], sh["cnt"][rows] = midx[mine], mcnt[mine]
     sh["d2"][rows] = engine.cast_like(md2[mine], sh["d2"])
-    sh["avg"][rows] = avg[mine]
+    if "avg" in sh:
+        sh["avg"][rows] = avg[mine]
     if want_normals:
         sh["normals"][rows] = nrm[mine]
     sh["n_repeated"] = total
@@ -239,15 +241,40 @@ def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank
     return sh, kept, stats
 
 
-def knn_slab(engine, pts, k: int, cache: dict, rank: int, world: int, **search_kw):
-    """kNN rows of the rank's z interval from an index of its own slab, or ``None`` where slabs do not pay or
-    this rank's slab cannot vouch for all its answers (the caller then uses ``knn_sharded``)."""
+def knn_slab_steps(engine, pts, k: int, cache: dict, rank: int, world: int, **search_kw):
+    """kNN rows of the rank's z interval from an index of its own slab (a generator like the others here: drive
+    it with ``run``).  The ranks decide TOGETHER what happens to answers no slab can vouch for: their number is
+    summed over the ranks, a few are repeated across the ranks (``_repeat_unvouched``, exact), and if there are
+    too many -- or slabs do not pay for this cloud, which every rank finds alike from the same cloud -- every rank
+    returns ``None`` and the caller uses ``knn_sharded`` on all ranks.  Never one rank's slab rows beside another
+    rank's slice of the replicated index: the two partitions of the cloud differ."""
     plan = slab_cuts(engine, pts, cache, k, world)
     if plan is None:
         return None
     cuts, halo = plan
+    n = len(pts)
     sh = engine.slab_search(pts, cache, k, -1.0, cuts[rank], cuts[rank + 1], halo, **search_kw)
-    return sh if sh["n_uncertain"] == 0 else None
+    count = engine.zeros((1,), "f64")
+    count[0] = float(sh["n_uncertain"])
+    count = yield count
+    total = int(float(count[0]))
+    if total > min(SLAB_REPEAT_MAX, max(n // 32, 1)):
+        return None
+    if total > 0:
+        yield from _repeat_unvouched(engine, pts, cache, k, sh, None, rank, world, total, False)
+    return sh
+
+
+def knn_slab(engine, pts, k: int, cache: Optional[dict] = None, group=None, **search_kw):
+    """``knn_slab_steps`` over the ranks of ``group``; falls back to ``knn_sharded`` on every rank alike."""
+    cache = {} if cache is None else cache
+    alone = not (dist.is_available() and dist.is_initialized())
+    rank, world = (0, 1) if alone else (dist.get_rank(group), dist.get_world_size(group))
+    sh = run(knn_slab_steps(engine, pts, k, cache, rank, world, **search_kw), group)
+    if sh is None:
+        b, e = shard_positions(len(pts), rank, world)
+        sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_rows=True, **search_kw)
+    return sh
 
 
 def sor_sharded(engine, pts, k: int, std_ratio: float, cache: Optional[dict] = None, group=None):

@@ -357,7 +357,14 @@ class HipEngine:
         device.  A cloud held as fp32 (exactly representable coordinates) stays fp32: the child's index is
         built from the gathered fp32 rows."""
         if not isinstance(idx, torch.Tensor):
-            idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+            # indices a caller supplies are checked like NumPy checks them (the gather kernel reads what it is told to)
+            host = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1)
+            rows = next(iter(arrs.values())).shape[0] if arrs else 0
+            if host.size and (int(host.min()) < -rows or int(host.max()) >= rows):
+                bad = int(host.max()) if int(host.max()) >= rows else int(host.min())
+                raise IndexError(f"index {bad} is out of bounds for a cloud of {rows} points")
+            host = np.where(host < 0, host + rows, host)  # (negative indices count from the end, as on the host path)
+            idx = torch.from_numpy(host.astype(np.int32)).to(self.device)
         out = {}
         for name, a in arrs.items():
             xyz = cache.get("xyz") if name == "points" else None

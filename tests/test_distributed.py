@@ -264,3 +264,69 @@ def test_slab_pipeline_on_the_hip_engine(hip, oracle, name):
     if name == "uniform":
         assert PD.slab_cuts(hip, pts, {}, k, 8) is not None
         assert all(s == stats[0] for s in stats)
+
+
+def _one_sided_strays():
+    """A uniform cloud with a few points far off to the side near its top: only the TOP slab meets answers it
+    cannot vouch for (their neighbours lie farther away than its open lower face)."""
+    rng = np.random.default_rng(12)
+    side = np.stack([4.0 + rng.random(5), rng.random(5), 0.93 + 0.05 * rng.random(5)], axis=1)
+    return np.concatenate([D.uniform_cube(30000, 11), side]).astype(np.float32).astype(np.float64)
+
+
+def _check_knn_slab(pts, res, k, oracle):
+    host = lambda a: a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+    ridx, rd2, rcnt = oracle.knn(pts, None, k)
+    seen = np.zeros(len(pts), dtype=int)
+    for sh in res:
+        owned = host(sh["owned"])
+        own = owned >= 0
+        o = owned[own]
+        assert np.array_equal(host(sh["idx"])[own], ridx[o]) and np.array_equal(host(sh["d2"])[own], rd2[o])
+        assert np.array_equal(host(sh["cnt"])[own], rcnt[o])
+        seen[o] += 1
+    assert (seen == 1).all()  # every point answered exactly once, whatever route the ranks agreed on
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_knn_slab_ranks_decide_together(oracle, world):
+    """Only one rank has answers it cannot vouch for: all ranks still take the same branch (the repeat across
+    the ranks), and the ranks' own rows cover the cloud exactly once."""
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd import distributed as PD
+
+    pts, k = _one_sided_strays(), 8
+    eng = OracleEngine()
+    cuts, halo = PD.slab_cuts(eng, pts, {}, k, world)
+    unc = [eng.slab_search(pts, {}, k, -1.0, cuts[r], cuts[r + 1], halo)["n_uncertain"] for r in range(world)]
+    assert unc[-1] > 0 and not any(unc[:-1])  # the premise: one rank only
+    res = PD.run_emulated(lambda r: PD.knn_slab_steps(OracleEngine(), pts, k, {}, r, world), world)
+    assert all(sh is not None and sh.get("n_repeated", 0) == unc[-1] for sh in res)
+    _check_knn_slab(pts, res, k, oracle)
+
+
+def test_knn_slab_too_many_unvouched_sends_every_rank_to_the_replicated_index(oracle, monkeypatch):
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd import distributed as PD
+
+    pts, k, world = _one_sided_strays(), 8, 2
+    monkeypatch.setattr(PD, "SLAB_REPEAT_MAX", 2)  # (fewer than the five strays)
+    res = PD.run_emulated(lambda r: PD.knn_slab_steps(OracleEngine(), pts, k, {}, r, world), world)
+    assert res == [None, None]  # all ranks alike: never one rank's slab rows beside another's slice
+    eng = OracleEngine()
+    res = [eng.shard_search(pts, {}, k, -1.0, *PD.shard_positions(len(pts), r, world), want_rows=True) for r in range(world)]
+    _check_knn_slab(pts, res, k, oracle)
+
+
+@pytest.mark.gpu
+def test_knn_slab_ranks_decide_together_on_the_hip_engine(hip, oracle):
+    from point_cloud_processing_amd import distributed as PD
+
+    rng = np.random.default_rng(12)
+    side = np.stack([4.0 + rng.random(5), rng.random(5), 0.93 + 0.05 * rng.random(5)], axis=1)
+    pts = np.concatenate([D.uniform_cube(300000, 11), side]).astype(np.float32).astype(np.float64)
+    for world in (2, 3):
+        cache = {}
+        res = PD.run_emulated(lambda r: PD.knn_slab_steps(hip, pts, 8, cache, r, world), world)
+        assert all(sh is not None and sh.get("n_repeated", 0) > 0 for sh in res)
+        _check_knn_slab(pts, res, 8, oracle)

@@ -188,6 +188,31 @@ def test_config4_at_full_size(hip):
         r = int(row_of[q])
         assert np.array_equal(want, idx[r].cpu().numpy()) and np.array_equal(dd[want].float().cpu().numpy(), d2[r].cpu().numpy())
         assert abs(float(sh["avg"][r]) - float(torch.sqrt(dd[want]).sum() / K)) < 1e-12
+    # the statistical filter at this size (reference: filtering_adapter.py:91), recomputed independently with torch in
+    # fp64 on the device: mean over the valid points, Bessel standard deviation, threshold, kept set
+    avg_full = torch.empty(mm, dtype=torch.float64, device=hip.device)
+    avg_full[owned.long()] = sh["avg"]
+    pos = avg_full > 0
+    valid = int((avg_full >= 0).sum())
+    mean = float(avg_full[pos].sum()) / valid
+    std = float(torch.sqrt(((avg_full[pos] - mean) ** 2).sum() / (valid - 1)))
+    thr = mean + 2.0 * std
+    want_kept = torch.nonzero(pos & (avg_full < thr)).flatten()
+
+    def same_filter(kept, stats):
+        assert stats[3] == valid and abs(stats[0] - mean) <= 1e-12 * mean and abs(stats[1] - std) <= 1e-11 * std
+        got = kept._dev.long()
+        flips = abs(got.numel() - want_kept.numel())
+        if flips == 0:
+            flips = int((got != want_kept).sum())
+        assert flips <= 2  # (a mean distance within an ulp of the threshold may fall either side of the other sum's threshold)
+        assert 0.02 * mm < mm - got.numel() < 0.2 * mm  # the filter removes the clutter's share, not nothing and not most
+
+    same_filter(*PD.run(PD._filter_core(hip, cent, cache, K, 2.0, sh, 0, mm)))  # the replicated index's chunked sums
+    box = torch.zeros(mm + 1, dtype=torch.float64, device=hip.device)
+    box[:mm] = avg_full
+    same_filter(*hip.sor_from_avg(box, mm, 2.0))                                 # the slab path's sums over the whole array
+    del box, pos, want_kept
     # one rank of eight through the slab path: its own index of its own part of the cloud, the same rows
     cuts, halo = PD.slab_cuts(hip, cent, cache, K, 8)
     sl = hip.slab_search(cent, cache, K, -1.0, cuts[3], cuts[4], halo, want_avg=True, d2_dtype=torch.float32)
