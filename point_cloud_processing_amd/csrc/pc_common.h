@@ -39,6 +39,7 @@ struct PcKnobs {
     int64_t mixed_min = 1ll << 20; // PC_AMD_MIXED_MIN
     uint32_t full_tile = 32;       // PC_AMD_FULL_TILE
     bool no_finer = false;         // PC_AMD_NO_FINER
+    bool no_bucket_build = false;  // PC_AMD_NO_BUCKET_BUILD: always the general index build (A/B switch)
 };
 PcKnobs pc_read_knobs();
 
@@ -226,6 +227,12 @@ int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq,
 // workgroup, *pop = expected queries per tile.  Pure arithmetic: the grid build uses it to pick, among cell edges
 // within a few per cent of each other, the one whose tiles divide the grid best.
 void pc_dense_tile_shape(const pc_ctx *ctx, double occ, const int32_t dim[3], int tile[3], int *waves, double *pop);
+
+// pc_build.hip
+// records, index map and cell table of an evenly filled fp32 cloud on a dense grid (see the file's head)
+int pc_build_bucketed(pc_ctx *ctx, const float *xyz, int64_t n, const GridParams &gp, int64_t ncell, int halfbit,
+                      Rec32 *rec_out, int32_t *perm_out, uint32_t *cell_start_out, unsigned long long *stats_dev,
+                      hipStream_t st, int *taken);
 
 // pc_sort.hip
 // device address of this GPU's copy of the static scratch array behind pc_sor_select_static (once per device)

@@ -96,6 +96,7 @@ PcKnobs pc_read_knobs() {
         k.mixed_min = num("PC_AMD_MIXED_MIN", 1ll << 20);
         k.full_tile = (uint32_t)num("PC_AMD_FULL_TILE", 32);
         k.no_finer = on("PC_AMD_NO_FINER");
+        k.no_bucket_build = on("PC_AMD_NO_BUCKET_BUILD");
         return k;
     }
 }
@@ -895,7 +896,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             rc = pc_fail(ctx, PC_NOMEM, "grid scratch");
             break;
         }
-        bool in_tmp = false, dense = true;
+        bool in_tmp = false, dense = true, built_direct = false;
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
         // Where smaller cells separate nothing -- as many occupied cells as before: the crowd in a cell is copies
@@ -916,6 +917,36 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             const int halfbit = (!parent && automatic && dense && dtype == PC_F32 && g->ncell < (1ll << 31) && k_hint > 2 &&
                                  !ctx->knobs.no_halves) ? 1 : 0;
             g->halves = halfbit != 0;
+            unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
+            built_direct = false;
+            if (!parent && dtype == PC_F32 && dense && !ctx->knobs.no_bucket_build) {
+                // an evenly filled fp32 cloud: records, index map and cell table in two moves of the records
+                // (pc_build.hip); a cloud that crowds one bucket or one cell takes the general route below
+                if (g->cell_start) ctx->release(g->cell_start);
+                cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
+                g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
+                if (!g->rec) g->rec = ctx->alloc(rec_bytes);
+                if (!g->perm) g->perm = (int32_t *)ctx->alloc(perm_bytes);
+                if (!g->cell_start || !g->rec || !g->perm) {
+                    rc = pc_fail(ctx, PC_NOMEM, "grid buffers");
+                    break;
+                }
+                int taken = 0;
+                rc = pc_build_bucketed(ctx, (const float *)xyz_dev, n, g->gp, g->ncell, halfbit, (Rec32 *)g->rec, g->perm,
+                                       g->cell_start, stats.as<unsigned long long>(), st, &taken);
+                if (rc) break;
+                if (taken) {
+                    if (hipMemcpyAsync(hs, stats.p, 3 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess) {
+                        rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
+                        break;
+                    }
+                    built_direct = hs[2] == 0;
+                    if (ctx->knobs.debug)
+                        fprintf(stderr, "[pc_amd]   bucketed build: %s\n", built_direct ? "taken" : "a bucket or cell overflowed, general build");
+                }
+            }
+            if (!built_direct) {
             if (parent && dtype == PC_F32)
                 hipLaunchKernelGGL(k_cell_keys32_rec<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
                                    (const Rec32 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
@@ -953,7 +984,6 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                 hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start,
                                    halfbit);
             }
-            unsigned long long *hs = reinterpret_cast<unsigned long long *>(ctx->pinned);
             // (a level made from another level has its cell edge given: nothing here waits for the numbers)
             const bool defer = parent != nullptr && !automatic;
             unsigned long long *sdev = stats.as<unsigned long long>();
@@ -981,6 +1011,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                 rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
                 break;
             }
+            }  // (general route)
             double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
             g->seen = seen;
@@ -1011,8 +1042,8 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
         if (n == 0) dense = true;
         if (!dense) cs_bytes = sizeof(uint32_t) * (size_t)std::max<int64_t>(n, 1);
-        g->rec = ctx->alloc(rec_bytes);
-        g->perm = (int32_t *)ctx->alloc(perm_bytes);
+        if (!g->rec) g->rec = ctx->alloc(rec_bytes);
+        if (!g->perm) g->perm = (int32_t *)ctx->alloc(perm_bytes);
         if (n == 0) {
             cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
             g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
@@ -1027,6 +1058,10 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         if (n == 0) {
             if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess)
                 rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell_start");
+            break;
+        }
+        if (built_direct) {
+            // (everything is in place; the caller's array may change once this returns: the last read-back waited)
             break;
         }
         const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
