@@ -270,7 +270,48 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     row_key[lane] = my_row_key;
     if (lane == 0) row_off[MAX_ROWS] = ncand;
     __syncthreads();
-    if (!overfull) {
+    if (!overfull && !UNEVEN) {
+        // Tiles of an evenly filled grid: a block row holds a few dozen candidates, so a wave copies whole rows, one
+        // row per step with lane = candidate of the row, the rows' parameters read from lane r of the row table
+        // (uniform), up to eight rows' loads in flight.  No per-candidate search for the row: the flattened loop
+        // below spends 28 vector instructions per candidate on that, this one 3 (569 -> about 190 per wave of the
+        // 10 M cloud's kernel).  The rare row of more than 64 candidates finishes in a loop of its own.
+        const int nwaves = nthr >> 6;
+        constexpr int ROWS_AT_ONCE = 8;
+        for (int r0 = wid; r0 < nrows; r0 += ROWS_AT_ONCE * nwaves) {  // uniform
+            float4 v[ROWS_AT_ONCE];
+            uint32_t dst[ROWS_AT_ONCE];
+#pragma unroll
+            for (int b = 0; b < ROWS_AT_ONCE; b++) {
+                const int r = min(r0 + b * nwaves, nrows - 1);
+                const uint32_t src0 = __builtin_amdgcn_readlane(row_begin, r), cnt_r = __builtin_amdgcn_readlane(row_cnt, r),
+                               dst0 = __builtin_amdgcn_readlane(cand_off, r);
+                const bool have = r0 + b * nwaves < nrows && (uint32_t)lane < cnt_r;
+                dst[b] = have ? dst0 + lane : 0xffffffffu;
+                v[b] = TileRec<REC>::stage(rec, have ? src0 + lane : 0u, org);  // (record 0 exists: the tile has queries)
+            }
+#pragma unroll
+            for (int b = 0; b < ROWS_AT_ONCE; b++) {
+                if (dst[b] != 0xffffffffu) {
+                    cxyz[3 * dst[b]] = v[b].x;
+                    cxyz[3 * dst[b] + 1] = v[b].y;
+                    cxyz[3 * dst[b] + 2] = v[b].z;
+                    cws[dst[b]] = v[b].w;
+                }
+            }
+        }
+        for (int r = wid; r < nrows; r += nwaves) {  // what a long row has beyond its first 64 candidates
+            const uint32_t src0 = __builtin_amdgcn_readlane(row_begin, r), cnt_r = __builtin_amdgcn_readlane(row_cnt, r),
+                           dst0 = __builtin_amdgcn_readlane(cand_off, r);
+            for (uint32_t o = PC_WAVE + lane; o < cnt_r; o += PC_WAVE) {
+                const float4 w = TileRec<REC>::stage(rec, src0 + o, org);
+                cxyz[3 * (dst0 + o)] = w.x;
+                cxyz[3 * (dst0 + o) + 1] = w.y;
+                cxyz[3 * (dst0 + o) + 2] = w.z;
+                cws[dst0 + o] = w.w;
+            }
+        }
+    } else if (!overfull) {
         int r = 0;
         for (uint32_t base = 0; base < ncand; base += 4 * nthr) {
             uint32_t src[4];
