@@ -265,6 +265,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     // ---- stage the candidate block into LDS ------------------------------------------------------
     // flattened over the block's candidates: lane i copies candidates i, i+64, ...; the row of a
     // candidate follows from the row offsets, and four 16-byte loads are in flight per lane
+#if defined(ABL_STAGE) && ABL_STAGE == 1
+    if (ncand != 0xdeadbeefu) return 0;
+#endif
     row_src[lane] = row_begin;
     row_off[lane] = cand_off;
     row_key[lane] = my_row_key;
@@ -339,6 +342,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
         }
     }
+#if defined(ABL_STAGE) && ABL_STAGE == 2
+    if (ncand != 0xdeadbeefu) return 0;
+#endif
     // Two sentinel candidates behind the block, infinitely far away: the filter reads candidates in pairs and may
     // read one past the end of a row segment (see stage 1).
     if (!overfull && tid < 6) cxyz[3 * ncand + tid] = 1e30f;
@@ -350,6 +356,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             cell_off[e] = (uint16_t)(row_off[r] + (cell_begin(A.ci, (int64_t)row_key[r] + lo[0] + i) - row_src[r]));
     }
     __syncthreads();
+#if defined(ABL_STAGE) && ABL_STAGE == 3
+    if (ncand != 0xdeadbeefu) return 0;
+#endif
     if (halves) {
         // first high-half record of every block cell (the records of a cell are ordered by that bit)
         for (int e = tid; e < nrows * (MAX_NX + 1); e += nthr) {
@@ -880,11 +889,13 @@ void k_tile_scan(ScanArgs A) {
         const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = bid & 7u;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    int64_t t = A.tile_list ? (int64_t)A.tile_list[bid] : (int64_t)bid + A.tile_base;
-    const int tx = (int)(t % A.ntile[0]);
-    t /= A.ntile[0];
-    const int ty = (int)(t % A.ntile[1]);
-    const int tz = (int)(t / A.ntile[1]);
+    // (tile ids are below 2^31 -- the launch checks it --: 32-bit divisions, a third of the 64-bit ones' instructions)
+    const uint32_t t = A.tile_list ? A.tile_list[bid] : bid + (uint32_t)A.tile_base;
+    const uint32_t n0 = (uint32_t)A.ntile[0], n1 = (uint32_t)A.ntile[1];
+    const uint32_t t1 = t / n0;
+    const int tx = (int)(t - t1 * n0);
+    const int tz = (int)(t1 / n1);
+    const int ty = (int)(t1 - (uint32_t)tz * n1);
     const int c0[3] = {tx * A.tile[0], ty * A.tile[1], tz * A.tile[2]};  // first cell of the tile
     const int ext[3] = {A.tile[0], A.tile[1], A.tile[2]};
     if (!SPLIT) {  // (clouds that fill their box: the tile shape was sized for the LDS capacity)
