@@ -409,7 +409,7 @@ def bench_c4(h):
         t("index_build_ms", lambda: eng.grid(cent, cache, K))
         sh = t("search_ms", lambda: eng.shard_search(cent, cache, K, -1.0, b, e, want_rows=True, want_avg=True,
                                                       d2_dtype=torch.float32))
-        kept, stats = t("filter_ms", lambda: PD.run(PD._filter_core(eng, cent, cache, K, 2.0, sh, b, e)))
+        kept, stats = t("filter_ms", lambda: PD.run(PD._filter_core(eng, sh, mm, 2.0)))
         return mm, len(kept), sh
 
     step()

@@ -166,6 +166,19 @@ int pc_sor_mask_scatter(pc_ctx *ctx, const double *avg_dev, const int32_t *owned
                         uint8_t *mask_dev, void *stream);
 int pc_mask_select(pc_ctx *ctx, const uint8_t *mask_dev, int64_t n, int32_t *out_kept_dev, int64_t *n_kept, void *stream);
 
+/* The statistical filter's sums without any summation order (reference: RemoveStatisticalOutliers behind
+ * app/Infrastructure/filtering_adapter.py:91 sums sequentially in index order; no parallel sum can follow that, so
+ * the library defines its own, exact one).  Every term -- avg (what = 0) or (avg - mean)^2 (what = 1) of the rows with
+ * avg > 0, and with owned >= 0 where owned_dev is given -- becomes a 256-bit fixed-point number of 2^-128 resolution,
+ * cut into eight 32-bit digits that are ADDED as integers into words_dev[0..7] (digit j weighs 2^(32 j - 128));
+ * words_dev[8] += rows with avg >= 0 (what = 0); words_dev[9] += terms of 2^96 or more (not representable: take
+ * pc_sor_sum / pc_sor_sqsum then).  The caller zeroes the PC_SOR_EXACT_WORDS words before a sum begins; ranks of a
+ * multi-GPU job add their words elementwise (all-reduce of 80 bytes).  The value is sum_j words[j] * 2^(32 j - 128),
+ * the same bits for any number of ranks and any cut of the cloud. */
+#define PC_SOR_EXACT_WORDS 10
+int pc_sor_exact_sums(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, int what, double mean,
+                      int64_t *words_dev, void *stream);
+
 /* Deterministic partial sums over avg[0..n): *sum_pos = sum of avg > 0, *n_valid = #(avg >= 0). */
 int pc_sor_sum(pc_ctx *ctx, const double *avg_dev, int64_t n, double *sum_pos, int64_t *n_valid, void *stream);
 /* *sq = sum over avg > 0 of (avg - mean)^2. */

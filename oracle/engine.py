@@ -199,39 +199,49 @@ class OracleEngine:
         return avg, nrm
 
     def sor_from_avg(self, avg, n, std_ratio):
+        from point_cloud_processing_amd.distributed import exact_value
+
         avg = np.asarray(avg)[:n]
-        pos = avg[avg > 0]
-        valid = int((avg >= 0).sum())
+        total, valid, _ = exact_value(self.exact_sums(avg, None, 0, 0.0))
         if valid == 0:
             return self.no_indices(), (0.0, 0.0, 0.0, 0)
-        mean = float(pos.sum()) / valid
+        mean = total / (valid << 128)
+        sq, _, _ = exact_value(self.exact_sums(avg, None, 1, mean))
         with np.errstate(divide="ignore", invalid="ignore"):
-            std = float(np.sqrt(((pos - mean) ** 2).sum() / np.float64(valid - 1)))
+            std = float(np.sqrt(np.float64(sq / (1 << 128)) / np.float64(valid - 1)))
         thr = mean + std_ratio * std
         return np.nonzero((avg > 0) & (avg < thr))[0], (mean, std, thr, valid)
 
-    def chunk_sums(self, pts, cache, k, avg, b, e, what, mean, compact=True):
-        from point_cloud_processing_amd.distributed import SOR_CHUNK
-
-        n = len(pts)
-        part = np.zeros(2 * ((n + SOR_CHUNK - 1) // SOR_CHUNK))
-        for c in range(b // SOR_CHUNK, (e + SOR_CHUNK - 1) // SOR_CHUNK):
-            v = avg[c * SOR_CHUNK - b:min((c + 1) * SOR_CHUNK, e) - b]
-            pos = v[v > 0]
-            part[2 * c] = pos.sum() if what == 0 else ((pos - mean) ** 2).sum()
-            part[2 * c + 1] = float((v >= 0).sum()) if what == 0 else 0.0
-        return part
-
-    def chunk_finish(self, part):
-        a = b = 0.0
-        for c in range(len(part) // 2):  # (fixed order)
-            a += part[2 * c]
-            b += part[2 * c + 1]
-        return a, b
+    def exact_sums(self, avg, owned, what, mean):
+        """The words of pc_sor_exact_sums, restated with Python integers: every term as floor(term * 2^128) where the
+        term has bits below 2^-128 (its mantissa shifted right), exactly term * 2^128 otherwise; the total cut into
+        32-bit digits."""
+        avg = np.asarray(avg, dtype=np.float64)
+        sel = avg > 0 if owned is None else (avg > 0) & (np.asarray(owned) >= 0)
+        ok = avg >= 0 if owned is None else (avg >= 0) & (np.asarray(owned) >= 0)
+        v = avg[sel]
+        if what == 1:
+            d = v - np.float64(mean)
+            v = d * d
+        fits = np.isfinite(v) & (v < 2.0 ** 96)
+        total, big = 0, int((~fits).sum())
+        mant, exp = np.frexp(v[fits])                 # v = mant * 2^exp, 0.5 <= mant < 1
+        m53 = (mant * (1 << 53)).astype(np.int64)     # exact
+        for m, e in zip(m53.tolist(), exp.tolist()):
+            sh = e - 53 + 128
+            total += (m << sh) if sh >= 0 else (m >> -sh)
+        words = np.zeros(10, dtype=np.int64)
+        for j in range(8):
+            words[j] = (total >> (32 * j)) & 0xffffffff
+        assert total >> 256 == 0
+        words[8] = int(ok.sum()) if what == 0 else 0
+        words[9] = big
+        return words
 
     def mask_scatter(self, avg, owned, thr, n):
         mask = np.zeros(n, dtype=np.uint8)
-        mask[owned] = (avg > 0) & (avg < thr)
+        own = np.asarray(owned) >= 0  # (a slab's rows of a neighbouring rank carry -1)
+        mask[np.asarray(owned)[own]] = ((np.asarray(avg) > 0) & (np.asarray(avg) < thr))[own]
         return mask
 
     def mask_select(self, mask, n):

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PC_AMD_LIB") or os.path.join(_HERE, "libpc_amd.so")  
 PC_F32, PC_F64 = 0, 1
 PC_MAX_K = 64
 PC_SOR_CHUNK = 4096
+PC_SOR_EXACT_WORDS = 10
 PC_SOR_SELECT_STATIC_MAX_N = 4 * 1024 * 1024
 
 # every symbol include/pc_amd.h declares: (name, restype, argtypes)
@@ -48,6 +49,7 @@ SYMBOLS = [
     ("pc_mask_bytes", _i64, [_i64]),
     ("pc_sor_mask_scatter", _i32, [_vp, _vp, _vp, _i64, _dbl, _vp, _vp]),
     ("pc_mask_select", _i32, [_vp, _vp, _i64, _vp, _pi64, _vp]),
+    ("pc_sor_exact_sums", _i32, [_vp, _vp, _vp, _i64, _i32, _dbl, _vp, _vp]),
     ("pc_sor_sum", _i32, [_vp, _vp, _i64, _pd, _pi64, _vp]),
     ("pc_sor_sqsum", _i32, [_vp, _vp, _i64, _dbl, _pd, _vp]),
     ("pc_sor_select", _i32, [_vp, _vp, _i64, _dbl, _vp, _vp, _pi64, _vp]),

@@ -312,6 +312,69 @@ __global__ __launch_bounds__(256) void k_sor_chunk_sums(const double *__restrict
     }
 }
 
+// ---- the same sums, exact: no tree at all --------------------------------------------------------------
+// Every term is turned into a 256-bit fixed-point number (2^-128 resolution: every bit of a double of 2^-76 or more;
+// smaller terms lose the bits below 2^-128, each on its own, whatever its neighbours), cut into eight 32-bit digits,
+// and the digits are added as integers -- per thread, per wave, then atomically into eight 64-bit words (room for
+// 2^31 terms).  Integer addition does not care about order or grouping: one GPU, eight GPUs with any cut of the
+// cloud, and a host restatement arrive at the same words, hence at the same mean and standard deviation, bit for bit.
+// words[8] counts the rows with avg >= 0 (what = 0), words[9] the terms too large for the format (>= 2^96: the
+// caller then takes the floating-point tree instead).
+__device__ inline void exact_digits_add(double v, unsigned long long (&acc)[8], unsigned long long &too_big) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const int be = (int)(bits >> 52) & 0x7ff;
+    unsigned long long m = (bits & ((1ull << 52) - 1)) | (be ? (1ull << 52) : 0ull);
+    int sh = (be ? be : 1) - 1075 + 128;  // v = m * 2^(sh - 128)
+    if (sh > 96 + 75) {  // v >= 2^96 (or not a number): not representable here
+        too_big += 1;
+        return;
+    }
+    if (sh < 0) {
+        m = sh > -64 ? m >> (-sh) : 0ull;
+        sh = 0;
+    }
+    const int d = sh >> 5, r = sh & 31;
+    const unsigned long long lo = m << r;                      // low 64 bits of m << r
+    const unsigned long long hi = r > 11 ? m >> (64 - r) : 0;  // the bits above them (m < 2^53)
+    const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32), d2 = (uint32_t)hi;
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] += (j == d ? d0 : 0u) + (unsigned long long)(j == d + 1 ? d1 : 0u) + (j == d + 2 ? d2 : 0u);
+}
+
+template <int WHAT>
+__global__ __launch_bounds__(256) void k_sor_exact(const double *__restrict__ avg, const int32_t *__restrict__ owned, int64_t m,
+                                                    double mean, unsigned long long *__restrict__ words) {
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt = 0, big = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        if (owned && owned[i] < 0) continue;  // (a slab's rows that belong to a neighbouring rank)
+        const double v = avg[i];
+        if (WHAT == 0) {
+            if (v > 0) exact_digits_add(v, acc, big);
+            if (v >= 0) cnt += 1;
+        } else if (v > 0) {
+            const double dv = v - mean;
+            exact_digits_add(dv * dv, acc, big);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_down(acc[j], o, 64);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_down(cnt, o, 64);
+        big += __shfl_down(big, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (acc[j]) atomicAdd(&words[j], acc[j]);
+        if (cnt) atomicAdd(&words[8], cnt);
+        if (big) atomicAdd(&words[9], big);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fill_slots(const int32_t *__restrict__ perm, int64_t s_begin, int64_t s_end,
                                                      int32_t *__restrict__ slot) {
     const int64_t s = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -467,6 +530,23 @@ int pc_sor_sqsum(pc_ctx *ctx, const double *avg_dev, int64_t n, double mean, dou
     double o[2];
     PC_TRY(sor_reduce(ctx, 1, avg_dev, n, mean, o, (hipStream_t)stream));
     *sq = o[0];
+    return PC_OK;
+}
+
+int pc_sor_exact_sums(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_dev, int64_t m, int what, double mean,
+                      int64_t *words_dev, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || m < 0 || (m > 0 && !avg_dev) || !words_dev || (what != 0 && what != 1) || ((uintptr_t)words_dev & 7u))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_sor_exact_sums");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (m == 0) return PC_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>(1024, (m + 255) / 256);
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(words_dev);
+    if (what == 0)
+        hipLaunchKernelGGL(k_sor_exact<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg_dev, owned_dev, m, mean, w);
+    else
+        hipLaunchKernelGGL(k_sor_exact<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg_dev, owned_dev, m, mean, w);
+    PC_HIP(hipGetLastError());
     return PC_OK;
 }
 

@@ -6,11 +6,13 @@ contiguous slice of the index's sorted positions -- spatially coherent, equally 
 multiples of the reduction chunk -- into outputs of ITS OWN size (rows in slice order plus the
 original index of every row).  kNN rows, normals and radius counts need no exchange at all.
 The statistical outlier filter has one real exchange step, its global mean and standard
-deviation: every rank fills the per-chunk partial sums of its own slice into a zeroed array, the
-arrays are added elementwise (RCCL all-reduce over xGMI when the backend is "nccl"; adding the
-other ranks' zeros is exact) and every rank finishes the same array with the same fixed tree, so
-the statistics carry the same bits for 1, 2, 4 or 8 ranks.  The outcome is exchanged the same
-way (one bit per point, set for the points a rank removes: the ranks' bits are disjoint, so the sum is the union).  Nothing else crosses GPUs, and nothing visits the host but a few scalars.
+deviation: every rank adds up its own rows as exact integer sums (``pc_sor_exact_sums``: ten 64-bit
+words), the words are added over the ranks (RCCL all-reduce over xGMI when the backend is "nccl")
+and every rank derives the same mean, standard deviation and threshold from the same integers --
+the same bits for 1, 2, 4 or 8 ranks, for slices of a replicated index and for z slabs alike.  The
+outcome is exchanged the same way (one bit per point, set for the points a rank removes: the ranks'
+bits are disjoint, so the sum is the union).  Nothing else crosses GPUs, and nothing visits the
+host but a few scalars.
 
 Each algorithm is written once, as a generator that yields the arrays it wants summed over the
 ranks: ``run`` drives it with ``dist.all_reduce``; ``run_emulated`` drives the generators of all
@@ -90,19 +92,34 @@ def run_emulated(make_gen, world: int):
 
 
 # ---- the algorithms ------------------------------------------------------------------------------
-def _filter_core(engine, pts, cache: dict, k: int, std_ratio: float, sh: dict, b: int, e: int):
-    """The exchange steps of the statistical filter, given a rank's mean distances ``sh["avg"]``."""
-    n = len(pts)
-    part = yield engine.chunk_sums(pts, cache, k, sh["avg"], b, e, 0, 0.0)
-    total, valid = engine.chunk_finish(part)
-    valid = int(valid)
+EXACT_WORDS = 10  # PC_SOR_EXACT_WORDS of the C ABI
+
+
+def exact_value(words) -> tuple:
+    """(sum as an exact integer multiple of 2^-128, count, terms too large for the format) of the words of
+    ``pc_sor_exact_sums``: digit j weighs 2^(32 j - 128)."""
+    w = [int(x) for x in np.asarray(words).reshape(-1)[:EXACT_WORDS]]
+    return sum(d << (32 * j) for j, d in enumerate(w[:8])), w[8], w[9]
+
+
+def _filter_core(engine, sh: dict, n: int, std_ratio: float):
+    """The exchange steps of the statistical filter, given a rank's own rows: mean distances ``sh["avg"]`` and the
+    original index ``sh["owned"]`` of every row (negative: a row that belongs to another rank).  The two sums are
+    exact integer sums (``pc_sor_exact_sums``): whatever the number of ranks and however the cloud was cut -- slices
+    of a replicated index, z slabs, one GPU -- mean, standard deviation and threshold carry the same bits."""
+    words = yield engine.exact_sums(sh["avg"], sh["owned"], 0, 0.0)
+    total, valid, big = exact_value(engine.to_host(words))
+    if big:
+        raise RuntimeError("[pc_amd] mean neighbour distances of 2^96 and more: outside the statistical filter's exact sums")
     if valid == 0:
         return engine.no_indices(), (0.0, 0.0, 0.0, 0)
-    mean = total / valid
-    part = yield engine.chunk_sums(pts, cache, k, sh["avg"], b, e, 1, mean)
-    sq, _ = engine.chunk_finish(part)
+    mean = total / (valid << 128)  # (integers: one correctly rounded division)
+    words = yield engine.exact_sums(sh["avg"], sh["owned"], 1, mean)
+    sq, _, big = exact_value(engine.to_host(words))
+    if big:
+        raise RuntimeError("[pc_amd] squared deviations of 2^96 and more: outside the statistical filter's exact sums")
     with np.errstate(divide="ignore", invalid="ignore"):
-        std = float(np.sqrt(np.float64(sq) / np.float64(valid - 1)))
+        std = float(np.sqrt(np.float64(sq / (1 << 128)) / np.float64(valid - 1)))
     thr = mean + std_ratio * std
     mask = yield engine.mask_scatter(sh["avg"], sh["owned"], thr, n)
     return engine.mask_select(mask, n), (mean, std, thr, valid)
@@ -112,7 +129,7 @@ def sor_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, wor
     """Statistical outlier removal of one rank (reference semantics: filtering_adapter.py:91)."""
     b, e = shard_positions(len(pts), rank, world)
     sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_avg=True)
-    return (yield from _filter_core(engine, pts, cache, k, std_ratio, sh, b, e))
+    return (yield from _filter_core(engine, sh, len(pts), std_ratio))
 
 
 def pipeline_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, want_normals: bool = True,
@@ -121,7 +138,7 @@ def pipeline_steps(engine, pts, k: int, std_ratio: float, cache: dict, rank: int
     outputs (rows, mean distances, normals, owned indices), the kept indices and the statistics."""
     b, e = shard_positions(len(pts), rank, world)
     sh = engine.shard_search(pts, cache, k, -1.0, b, e, want_rows=True, want_avg=True, want_normals=want_normals, **search_kw)
-    kept, stats = yield from _filter_core(engine, pts, cache, k, std_ratio, sh, b, e)
+    kept, stats = yield from _filter_core(engine, sh, len(pts), std_ratio)
     return sh, kept, stats
 
 
@@ -216,28 +233,28 @@ def _repeat_unvouched(engine, pts, cache: dict, k: int, sh: dict, box, rank: int
 def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank: int, world: int, want_normals: bool = True,
                         **search_kw):
     """``pipeline_steps`` with an index of the rank's own slab instead of a replicated one: rows, mean distances
-    and normals of the rank's z interval from ONE search of the slab, then one exchange -- the mean distances
-    put together (each rank fills its own rows of a zeroed array: adding the others' zeros is exact), with the
-    number of answers the slabs cannot vouch for riding along.  Those are repeated across the ranks
-    (``_repeat_unvouched``); if they are too many for that, the whole job goes to the replicated index: results are
-    exact either way.  Returns what ``pipeline_steps`` returns; rows with ``owned`` < 0 belong to a neighbouring
+    and normals of the rank's z interval from ONE search of the slab.  The ranks first add up the number of
+    answers their slabs cannot vouch for; those are repeated across the ranks (``_repeat_unvouched``), and if they
+    are too many for that, the whole job goes to the replicated index: results are exact either way.  The filter
+    then exchanges what ``_filter_core`` exchanges -- twice ten integer words and the bit mask of the removed
+    points --, never an array of the cloud's size.  Returns what ``pipeline_steps`` returns; rows with ``owned`` < 0 belong to a neighbouring
     rank."""
     plan = slab_cuts(engine, pts, cache, k, world)
     if plan is None:
         return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, want_normals, **search_kw))
     cuts, halo = plan
     n = len(pts)
-    box = engine.zeros_f64(n + 1)
     sh = engine.slab_search(pts, cache, k, -1.0, cuts[rank], cuts[rank + 1], halo, want_avg=True, want_normals=want_normals,
-                            avg_full=box, **search_kw)
-    box[n] = float(sh["n_uncertain"])
-    box = yield box
-    total = int(float(box[n]))
+                            **search_kw)
+    count = engine.zeros((1,), "f64")
+    count[0] = float(sh["n_uncertain"])
+    count = yield count
+    total = int(float(count[0]))
     if total > min(SLAB_REPEAT_MAX, max(n // 32, 1)):  # (the halo does not fit this cloud at all)
         return (yield from pipeline_steps(engine, pts, k, std_ratio, cache, rank, world, want_normals, **search_kw))
     if total > 0:
-        yield from _repeat_unvouched(engine, pts, cache, k, sh, box, rank, world, total, want_normals)
-    kept, stats = engine.sor_from_avg(box, n, std_ratio)
+        yield from _repeat_unvouched(engine, pts, cache, k, sh, None, rank, world, total, want_normals)
+    kept, stats = yield from _filter_core(engine, sh, n, std_ratio)
     return sh, kept, stats
 
 

@@ -290,26 +290,32 @@ class HipEngine:
             cache[key] = avg
         return avg
 
+    def exact_sums(self, avg: torch.Tensor, owned, what: int, mean: float) -> torch.Tensor:
+        """The ten integer words of ``pc_sor_exact_sums`` over the rows of ``avg`` (those with ``owned`` >= 0 where
+        ``owned`` is given): an order-free sum of avg (what = 0) or (avg - mean)^2 (what = 1) and the count."""
+        words = torch.zeros((_lib.PC_SOR_EXACT_WORDS,), dtype=torch.int64, device=self.device)
+        self._check(self.lib.pc_sor_exact_sums(self.ctx, _ptr(avg), _ptr(owned), avg.numel(), int(what), float(mean),
+                                               _ptr(words), self.stream()), "pc_sor_exact_sums")
+        return words
+
     def sor_stats(self, avg: torch.Tensor, std_ratio: float, pts=None, cache=None, k=None):
-        """(mean, std, threshold, valid) of the per-point mean distances.  With the cloud given, the sums run
-        over chunks of the index's sorted positions: the tree a multi-GPU job uses, so one GPU and eight give
-        the same bits.  Without it: over the array as it lies (pc_sor_sum / pc_sor_sqsum)."""
+        """(mean, std, threshold, valid) of the per-point mean distances from exact integer sums: the same bits
+        as a multi-GPU job finds for the same cloud, however it is cut (``distributed._filter_core``)."""
+        from .distributed import exact_value
+
         n = avg.numel()
-        if pts is not None:
-            total, valid = self.chunk_finish(self.chunk_sums(pts, cache, k, avg, 0, n, 0, 0.0, compact=False))
-            valid = int(valid)
-            if valid == 0:
-                return 0.0, 0.0, 0.0, 0
-            mean = total / valid
-            sq, _ = self.chunk_finish(self.chunk_sums(pts, cache, k, avg, 0, n, 1, mean, compact=False))
-        else:
+        total, valid, big = exact_value(self.exact_sums(avg, None, 0, 0.0).cpu().numpy())
+        if valid == 0:
+            return 0.0, 0.0, 0.0, 0
+        if not big:
+            mean = total / (valid << 128)
+            sq, _, big = exact_value(self.exact_sums(avg, None, 1, mean).cpu().numpy())
+            sq = sq / (1 << 128)
+        if big:  # distances of 2^96 and more: the floating-point tree over the array as it lies
             s = C.c_double(0)
             nv = C.c_int64(0)
-            self._check(self.lib.pc_sor_sum(self.ctx, _ptr(avg), n, C.byref(s), C.byref(nv), self.stream()),
-                        "pc_sor_sum")
+            self._check(self.lib.pc_sor_sum(self.ctx, _ptr(avg), n, C.byref(s), C.byref(nv), self.stream()), "pc_sor_sum")
             valid = nv.value
-            if valid == 0:
-                return 0.0, 0.0, 0.0, 0
             mean = s.value / valid
             q = C.c_double(0)
             self._check(self.lib.pc_sor_sqsum(self.ctx, _ptr(avg), n, mean, C.byref(q), self.stream()), "pc_sor_sqsum")
@@ -554,20 +560,6 @@ class HipEngine:
         self._check(self.lib.pc_sor_select(self.ctx, _ptr(avg), n, float(thr), None, _ptr(kept), C.byref(nk),
                                            self.stream()), "pc_sor_select")
         return LazyIndices(self, kept[: nk.value], nk.value), (mean, std, thr, valid)
-
-    def chunk_sums(self, pts, cache, k, avg, b, e, what, mean, compact=True) -> torch.Tensor:
-        """Zeroed partial-sum array of the whole cloud with the chunks of [b, e) filled in."""
-        g = self.grid(pts, cache, k)
-        part = torch.zeros((2 * int(self.lib.pc_sor_chunks(len(pts))),), dtype=torch.float64, device=self.device)
-        self._check(self.lib.pc_sor_chunk_sums(self.ctx, g.h, _ptr(avg), 1 if compact else 0, b, e, int(what), float(mean),
-                                               _ptr(part), self.stream()), "pc_sor_chunk_sums")
-        return part
-
-    def chunk_finish(self, part: torch.Tensor):
-        out = (C.c_double * 2)()
-        self._check(self.lib.pc_sor_chunk_finish(self.ctx, _ptr(part), part.numel() // 2, out, self.stream()),
-                    "pc_sor_chunk_finish")
-        return float(out[0]), float(out[1])
 
     def mask_scatter(self, avg, owned, thr, n) -> torch.Tensor:
         mask = torch.zeros((int(self.lib.pc_mask_bytes(n)),), dtype=torch.uint8, device=self.device)  # one bit per point, set = removed

@@ -219,8 +219,9 @@ def test_slab_pipeline_matches_whole_cloud(oracle, name):
         stats.append(_check_slab_results(pts, res, k, oracle, want_slab=slabbed))
         if name == "stray" and world == 2:  # the strays' answers were repeated across the ranks, not the whole job
             assert all(sh.get("n_repeated", 0) > 0 for sh, _, _ in res)
-    if name == "uniform":
-        assert stats[0] == stats[1] == stats[2]  # one fixed tree over the whole array: any world, same bits
+    # exact integer sums: whichever route a world took -- slabs, slabs with repeated answers, the replicated index --
+    # the statistics carry the same bits
+    assert stats[0] == stats[1] == stats[2]
 
 
 def test_slab_cuts_partition_and_balance(oracle):
@@ -263,7 +264,9 @@ def test_slab_pipeline_on_the_hip_engine(hip, oracle, name):
             assert slabbed and all(sh.get("n_repeated", 0) > 0 for sh, _, _ in res)
     if name == "uniform":
         assert PD.slab_cuts(hip, pts, {}, k, 8) is not None
-        assert all(s == stats[0] for s in stats)
+    assert all(s == stats[0] for s in stats)  # slabs or fallback, any world: the same bits
+    single = hip.sor_stats(hip.sor_avg_dev(pts, k, {}), 2.0)
+    assert tuple(single) == tuple(stats[0])   # ... and the one-GPU call's
 
 
 def _one_sided_strays():
@@ -330,3 +333,48 @@ def test_knn_slab_ranks_decide_together_on_the_hip_engine(hip, oracle):
         res = PD.run_emulated(lambda r: PD.knn_slab_steps(hip, pts, 8, cache, r, world), world)
         assert all(sh is not None and sh.get("n_repeated", 0) > 0 for sh in res)
         _check_knn_slab(pts, res, 8, oracle)
+
+
+def test_exact_sums_do_not_depend_on_order_or_cut(oracle):
+    """The statistical filter's integer sums: any permutation and any cut of the rows give the same words' value,
+    and that value is the exactly rounded sum."""
+    from fractions import Fraction
+
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd.distributed import exact_value
+
+    rng = np.random.default_rng(3)
+    v = np.concatenate([rng.random(5000) * 10.0 ** rng.integers(-12, 6, 5000), [0.0, -1.0, 5e-324, 2.0 ** -130, 2.0 ** 95, 1e-300]])
+    eng = OracleEngine()
+    whole = exact_value(eng.exact_sums(v, None, 0, 0.0))
+    assert whole[1] == int((v >= 0).sum()) and whole[2] == 0
+    want = sum(int(Fraction(float(x)) * 2 ** 128) for x in v if x > 0)  # floor(x * 2^128), term by term
+    assert whole[0] == want
+    perm = rng.permutation(len(v))
+    for cuts in ([0, len(v)], [0, 17, 4000, len(v)]):
+        words = sum(eng.exact_sums(v[perm][a:b], None, 0, 0.0) for a, b in zip(cuts[:-1], cuts[1:]))
+        assert exact_value(words) == whole
+    owned = np.where(np.arange(len(v)) % 3 == 0, -1, np.arange(len(v)))
+    part = exact_value(eng.exact_sums(v, owned, 1, 0.5))
+    d = v[(v > 0) & (owned >= 0)] - 0.5
+    assert part[0] == sum(int(Fraction(float(x)) * 2 ** 128) for x in d * d)
+    assert exact_value(eng.exact_sums(np.array([1.0, 2.0 ** 96, np.inf]), None, 0, 0.0))[2] == 2
+
+
+@pytest.mark.gpu
+def test_exact_sums_on_the_device_match_the_restatement(hip, oracle):
+    import torch
+    from oracle.engine import OracleEngine
+    from point_cloud_processing_amd.distributed import exact_value
+
+    rng = np.random.default_rng(4)
+    v = np.concatenate([rng.random(300000) * 10.0 ** rng.integers(-12, 6, 300000), [0.0, -1.0, 5e-324, 2.0 ** -130, 2.0 ** 95, 1e-300]])
+    owned = np.where(rng.random(len(v)) < 0.2, -1, np.arange(len(v))).astype(np.int32)
+    dv, do = torch.from_numpy(v).to(hip.device), torch.from_numpy(owned).to(hip.device)
+    eng = OracleEngine()
+    for what, mean in ((0, 0.0), (1, 0.37)):
+        for own_h, own_d in ((None, None), (owned, do)):
+            got = exact_value(hip.exact_sums(dv, own_d, what, mean).cpu().numpy())
+            assert got == exact_value(eng.exact_sums(v, own_h, what, mean))
+    big = torch.tensor([1.0, 2.0 ** 96, float("inf"), float("nan")], dtype=torch.float64, device=hip.device)
+    assert exact_value(hip.exact_sums(big, None, 0, 0.0).cpu().numpy())[2] == 2  # (nan is neither > 0 nor >= 0)

@@ -208,10 +208,10 @@ def test_config4_at_full_size(hip):
         assert flips <= 2  # (a mean distance within an ulp of the threshold may fall either side of the other sum's threshold)
         assert 0 < mm - got.numel() < 0.2 * mm  # the filter removes something and not most
 
-    same_filter(*PD.run(PD._filter_core(hip, cent, cache, K, 2.0, sh, 0, mm)))  # the replicated index's chunked sums
+    same_filter(*PD.run(PD._filter_core(hip, sh, mm, 2.0)))  # a rank's rows: exact integer sums, removed-bit mask
     box = torch.zeros(mm + 1, dtype=torch.float64, device=hip.device)
     box[:mm] = avg_full
-    same_filter(*hip.sor_from_avg(box, mm, 2.0))                                 # the slab path's sums over the whole array
+    same_filter(*hip.sor_from_avg(box, mm, 2.0))                 # the same sums over the array at the original index
     del box, pos, want_kept
     # one rank of eight through the slab path: its own index of its own part of the cloud, the same rows
     cuts, halo = PD.slab_cuts(hip, cent, cache, K, 8)

@@ -329,6 +329,7 @@ def test_sharded_filter_carries_the_same_bits_for_any_world(hip, oracle, name):
             first = first or stats
             assert stats == first  # bit-identical (mean, std, threshold, valid)
         np.testing.assert_allclose(first[:3], rstats[:3], rtol=1e-12)
+    assert tuple(hip.sor_stats(hip.sor_avg_dev(p, 20, {}), 2.0)) == tuple(first)  # the one-GPU call: the same bits
     nrm = PD.run_emulated(lambda r: PD.normals_steps(hip, p, 16, -1.0, {}, r, 3), 3)
     one = hip.normals(p, 16, -1.0, None, {})
     for x in nrm:
