@@ -106,18 +106,39 @@ def cpu_pipeline_baseline(points: np.ndarray, k: int, std_ratio: float, voxel=No
                       f"(own search), normals (own search), kept {len(kept)}"}
 
 
-def pmc_traffic(n, k):
-    """HBM bytes per launch of the dominant kernel from the committed counter passes (FETCH_SIZE / WRITE_SIZE
-    are collected with rocprofv3 in runs of their own; they cannot be read in-process)."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+def _newest_profile(pattern):
+    """The newest committed profile summary matching the glob (profiles/ are named per round: r01_, r02_, ...)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             with open(path) as f:
-                pmc = json.load(f)
+                return json.load(f), os.path.relpath(path, ROOT)
         except (OSError, ValueError):
             continue
-        if pmc.get("points", 10_000_000) == n and pmc.get("k", 16) == k:
-            return pmc["traffic_bytes_per_launch"], os.path.relpath(path, ROOT) + " (rocprofv3 --pmc passes of this command)"
+    return None, None
+
+
+def pmc_traffic(n, k, pipeline=False):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes (FETCH_SIZE / WRITE_SIZE
+    are collected with rocprofv3 in runs of their own; they cannot be read in-process)."""
+    for pattern in (("r*_pmc_traffic_pipeline.json",) if pipeline else ("r*_pmc_traffic.json", "r*_pmc_traffic_c2.json")):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+            try:
+                with open(path) as f:
+                    pmc = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if pmc.get("points", 10_000_000) == n and pmc.get("k", 16) == k:
+                key = "traffic_bytes_per_launch_pipeline" if pipeline and "traffic_bytes_per_launch_pipeline" in pmc else "traffic_bytes_per_launch"
+                return pmc[key], os.path.relpath(path, ROOT) + " (rocprofv3 --pmc passes of this command)"
     return None, "not collected for this size"
+
+
+def config_traffic(tag, key="traffic_bytes_per_step"):
+    """Per-step HBM bytes (and whatever else the round's counter passes of `--config <tag>` recorded)."""
+    pmc, path = _newest_profile(f"r*_pmc_traffic_{tag}.json")
+    if pmc is None or key not in pmc:
+        return None, "not collected", {}
+    return pmc[key], path + " (rocprofv3 --pmc passes of this command)", pmc
 
 
 class Harness:
@@ -236,6 +257,15 @@ def bench_headline(h, n, k, label="kNN queries/sec (10M pts, k=16)", cloud=None)
         "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": alg, "kernel_ms": knn_ms, "kernel_queries_per_s": m / (knn_ms * 1e-3),
     }
+    sqp, sq_path = _newest_profile("r*_pmc_sq_tile_kernel.json")
+    if sqp and h.world == 1 and n == 10_000_000 and k == 16:
+        dv = sqp["derived"]
+        # what actually bounds the kernel: vector-instruction issue (one wave64 instruction per four cycles and SIMD)
+        result["roofline"]["valu_busy"] = dv.get("valu_busy_frac_of_kernel", dv["valu_issue_cycles_per_simd"] / (1.74e-3 * 2.4e9))
+        result["roofline"]["valu_instructions_per_wave"] = dv["valu_instructions_per_wave"]
+        result["roofline"]["valu_source"] = sq_path + " (SQ counters of the same command)"
+        result["roofline"]["bound_in_practice"] = ("vector-instruction issue: at 100 % issue the kernel would take valu_busy x its time, i.e. "
+                                                   "reach frac / valu_busy of the HBM roofline with this instruction count")
     result["step_parts_ms"] = {"index_build_replicated": build_ms, "knn_of_own_slice": knn_ms}
 
     if not args.no_pipeline:
@@ -267,6 +297,9 @@ def bench_headline(h, n, k, label="kNN queries/sec (10M pts, k=16)", cloud=None)
             "points_per_s": n / pt, "ms": pt * 1e3, "kept": len(kept), "algorithmic_bytes_per_point": 169,
             "hbm_frac": 169.0 * n / h.world / pt / 1e9 / HBM_PEAK_GBS,
         }
+        if h.world == 1:
+            tr, src = pmc_traffic(n, k, pipeline=True)
+            result["pipeline"]["traffic"], result["pipeline"]["traffic_source"] = tr, src
 
     if h.rank == 0 and h.world == 1 and not args.no_cpu:
         result["cpu_baseline"] = cpu_knn_baseline(pts64, k, min(args.cpu_sample, n))
@@ -343,6 +376,11 @@ def bench_c3(h):
                      "achieved": alg / (np.mean(lat_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / (np.mean(lat_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "traffic_source": "not collected", "algorithmic_bytes_per_launch": alg}
+    tr, src, pmc = config_traffic("c3")
+    r["roofline"]["traffic"], r["roofline"]["traffic_source"] = tr, src
+    if pmc:
+        r["launches_per_frame"] = pmc.get("launches_per_step")
+        r["kernel_time_us_per_frame"] = pmc.get("kernel_time_us_per_step")
     if not args.no_cpu:
         from oracle import pc_oracle as O
 
@@ -441,6 +479,9 @@ def bench_c4(h):
                      "kernel_ms": search_ms}
     if "search_ms" not in parts:
         r["roofline"]["kernel"] += " -- timed with the slab's subset, index and filter around it (slab path)"
+    elif n == 100_000_000 and h.world == 1:
+        tr, src, _ = config_traffic("c4")
+        r["roofline"]["traffic"], r["roofline"]["traffic_source"] = tr, src
     if not args.no_cpu and h.rank == 0:
         sample = 4_000_000
         p = D.planar_patches(sample, 5, extent=200.0 * (sample / n) ** (1.0 / 3.0))  # same density, smaller box
@@ -509,6 +550,12 @@ def bench_c5(h):
                      "achieved": alg / (knn_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": "not collected",
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": knn_ms}
+    if n == 2_000_000:
+        tr, src, pmc = config_traffic("c5")
+        r["roofline"]["traffic"], r["roofline"]["traffic_source"] = tr, src
+        if pmc:
+            r["binning_share_of_search_kernel_time"] = pmc.get("binning_share_of_search_kernel_time")
+            r["launches_per_iteration"] = pmc.get("launches_per_step")
     if not args.no_cpu:
         from oracle import pc_oracle as O
 

@@ -320,59 +320,115 @@ __global__ __launch_bounds__(256) void k_sor_chunk_sums(const double *__restrict
 // cloud, and a host restatement arrive at the same words, hence at the same mean and standard deviation, bit for bit.
 // words[8] counts the rows with avg >= 0 (what = 0), words[9] the terms too large for the format (>= 2^96: the
 // caller then takes the floating-point tree instead).
-__device__ inline void exact_digits_add(double v, unsigned long long (&acc)[8], unsigned long long &too_big) {
+// v as floor(v * 2^128): first 32-bit digit `d` (0..5) and the three digits from there on; false (nothing set) for a
+// value of 2^96 and more or no number at all
+__device__ inline bool exact_digits(double v, int &d, uint32_t &d0, uint32_t &d1, uint32_t &d2) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     const int be = (int)(bits >> 52) & 0x7ff;
     unsigned long long m = (bits & ((1ull << 52) - 1)) | (be ? (1ull << 52) : 0ull);
     int sh = (be ? be : 1) - 1075 + 128;  // v = m * 2^(sh - 128)
-    if (sh > 96 + 75) {  // v >= 2^96 (or not a number): not representable here
-        too_big += 1;
-        return;
-    }
+    d = 0;
+    d0 = d1 = d2 = 0;
+    if (sh > 96 + 75) return false;  // v >= 2^96, or not a number
     if (sh < 0) {
         m = sh > -64 ? m >> (-sh) : 0ull;
         sh = 0;
     }
-    const int d = sh >> 5, r = sh & 31;
+    d = sh >> 5;
+    const int r = sh & 31;
     const unsigned long long lo = m << r;                      // low 64 bits of m << r
     const unsigned long long hi = r > 11 ? m >> (64 - r) : 0;  // the bits above them (m < 2^53)
-    const uint32_t d0 = (uint32_t)lo, d1 = (uint32_t)(lo >> 32), d2 = (uint32_t)hi;
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc[j] += (j == d ? d0 : 0u) + (unsigned long long)(j == d + 1 ? d1 : 0u) + (j == d + 2 ? d2 : 0u);
+    d0 = (uint32_t)lo;
+    d1 = (uint32_t)(lo >> 32);
+    d2 = (uint32_t)hi;
+    return true;
 }
 
+constexpr int EXACT_BLOCKS = 1024, EXACT_AHEAD = 4;
 template <int WHAT>
 __global__ __launch_bounds__(256) void k_sor_exact(const double *__restrict__ avg, const int32_t *__restrict__ owned, int64_t m,
-                                                    double mean, unsigned long long *__restrict__ words) {
+                                                    double mean, unsigned long long *__restrict__ partial /*[blocks][10]*/) {
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt = 0, big = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
-        if (owned && owned[i] < 0) continue;  // (a slab's rows that belong to a neighbouring rank)
-        const double v = avg[i];
-        if (WHAT == 0) {
-            if (v > 0) exact_digits_add(v, acc, big);
-            if (v >= 0) cnt += 1;
-        } else if (v > 0) {
-            const double dv = v - mean;
-            exact_digits_add(dv * dv, acc, big);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < m; i0 += EXACT_AHEAD * stride) {
+        double v[EXACT_AHEAD];
+        int32_t o[EXACT_AHEAD];
+#pragma unroll
+        for (int u = 0; u < EXACT_AHEAD; u++) {  // all loads of the turn in flight together
+            const int64_t i = i0 + u * stride;
+            v[u] = i < m ? avg[i] : -1.0;
+            o[u] = owned && i < m ? owned[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < EXACT_AHEAD; u++) {
+            const bool mine = i0 + u * stride < m && o[u] >= 0;  // (a slab's rows of a neighbouring rank carry -1)
+            double term = v[u];
+            if (WHAT == 0) {
+                cnt += mine && v[u] >= 0 ? 1 : 0;
+            } else {
+                const double dv = v[u] - mean;
+                term = dv * dv;
+            }
+            int d;
+            uint32_t d0, d1, d2;
+            const bool want = mine && v[u] > 0;
+            const bool fits = exact_digits(want ? term : 0.0, d, d0, d1, d2);
+            big += want && !fits ? 1 : 0;
+            // The terms of one cloud lie within a few binades: as a rule every lane of the wave starts at the same
+            // digit, and three plain additions do (digits of lanes without a term are zero and fit anywhere).
+            const unsigned long long have = __ballot(want && fits);
+            if (have == 0) continue;  // uniform
+            const int dw = __builtin_amdgcn_readlane(d, (int)__builtin_ctzll(have));
+            if (__ballot(want && fits && d != dw) == 0) {
+                switch (dw) {  // uniform
+                    case 0: acc[0] += d0; acc[1] += d1; acc[2] += d2; break;
+                    case 1: acc[1] += d0; acc[2] += d1; acc[3] += d2; break;
+                    case 2: acc[2] += d0; acc[3] += d1; acc[4] += d2; break;
+                    case 3: acc[3] += d0; acc[4] += d1; acc[5] += d2; break;
+                    case 4: acc[4] += d0; acc[5] += d1; acc[6] += d2; break;
+                    default: acc[5] += d0; acc[6] += d1; acc[7] += d2; break;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    acc[j] += (unsigned long long)(j == d ? d0 : 0u) + (j == d + 1 ? d1 : 0u) + (j == d + 2 ? d2 : 0u);
+            }
         }
     }
+    __shared__ unsigned long long red[4][PC_SOR_EXACT_WORDS];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_down(acc[j], o, 64);
+        for (int o2 = 32; o2 > 0; o2 >>= 1) acc[j] += __shfl_down(acc[j], o2, 64);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        cnt += __shfl_down(cnt, o, 64);
-        big += __shfl_down(big, o, 64);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        cnt += __shfl_down(cnt, o2, 64);
+        big += __shfl_down(big, o2, 64);
     }
     if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (acc[j]) atomicAdd(&words[j], acc[j]);
-        if (cnt) atomicAdd(&words[8], cnt);
-        if (big) atomicAdd(&words[9], big);
+        for (int j = 0; j < 8; j++) red[w][j] = acc[j];
+        red[w][8] = cnt;
+        red[w][9] = big;
     }
+    __syncthreads();
+    if (threadIdx.x < PC_SOR_EXACT_WORDS)
+        partial[(size_t)blockIdx.x * PC_SOR_EXACT_WORDS + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// words[j] += sum over the blocks' partial words (integers: any order); wave j of the workgroup sums word j
+__global__ __launch_bounds__(64 * PC_SOR_EXACT_WORDS) void k_sor_exact_finish(const unsigned long long *__restrict__ partial,
+                                                                               int nblocks, unsigned long long *__restrict__ words) {
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long s = 0;
+#pragma unroll 8
+    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * PC_SOR_EXACT_WORDS + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) words[j] += s;
 }
 
 __global__ __launch_bounds__(256) void k_fill_slots(const int32_t *__restrict__ perm, int64_t s_begin, int64_t s_end,
@@ -540,12 +596,15 @@ int pc_sor_exact_sums(pc_ctx *ctx, const double *avg_dev, const int32_t *owned_d
         return pc_fail(ctx, PC_BAD_ARG, "pc_sor_exact_sums");
     PC_HIP(hipSetDevice(ctx->device));
     if (m == 0) return PC_OK;
-    const unsigned blocks = (unsigned)std::min<int64_t>(1024, (m + 255) / 256);
-    unsigned long long *w = reinterpret_cast<unsigned long long *>(words_dev);
+    const int blocks = (int)std::min<int64_t>(EXACT_BLOCKS, (m + 255) / 256);
+    Scratch part(ctx, sizeof(unsigned long long) * PC_SOR_EXACT_WORDS * (size_t)blocks);
+    if (!part.ok()) return pc_fail(ctx, PC_NOMEM, "exact sums scratch");
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(words_dev), *p = part.as<unsigned long long>();
     if (what == 0)
-        hipLaunchKernelGGL(k_sor_exact<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg_dev, owned_dev, m, mean, w);
+        hipLaunchKernelGGL(k_sor_exact<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg_dev, owned_dev, m, mean, p);
     else
-        hipLaunchKernelGGL(k_sor_exact<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg_dev, owned_dev, m, mean, w);
+        hipLaunchKernelGGL(k_sor_exact<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, avg_dev, owned_dev, m, mean, p);
+    hipLaunchKernelGGL(k_sor_exact_finish, dim3(1), dim3(64 * PC_SOR_EXACT_WORDS), 0, (hipStream_t)stream, p, blocks, w);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
