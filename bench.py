@@ -9,7 +9,7 @@ The cloud is resident in HBM before the timed region starts.
 --gpus N (launched by torch.distributed.run, one rank per GPU): ONE cloud; the index is replicated (every
 rank builds it) and rank r answers the queries of its slice of the index's sorted positions into outputs of
 the slice's own size.  kNN rows need no exchange; the pipeline leg (kNN + statistical filter + normals) has
-the filter's three small all-reduces over RCCL.  Total work is fixed: "scaling": "strong".
+the filter's three small all-reduces over RCCL (twice ten integer words, once the bit mask of the removed points).  Total work is fixed: "scaling": "strong".
 
 --config c2 | c3 | c4 | c5: the other BASELINE configurations (same JSON shape, their own metric).
 """
@@ -293,7 +293,7 @@ def bench_headline(h, n, k, label="kNN queries/sec (10M pts, k=16)", cloud=None)
             pt = float(t.item())
         result["pipeline"] = {
             "what": f"index build + ONE fused search of the rank's slice -> kNN({k}) rows + statistical filter (k={k}, std "
-                    "2.0: mean distances, chunked deterministic sums, all-reduce, kept mask, select) + normals(knn=k)",
+                    "2.0: mean distances, exact integer sums, all-reduce of ten words, removed-bit mask, select) + normals(knn=k)",
             "points_per_s": n / pt, "ms": pt * 1e3, "kept": len(kept), "algorithmic_bytes_per_point": 169,
             "hbm_frac": 169.0 * n / h.world / pt / 1e9 / HBM_PEAK_GBS,
         }

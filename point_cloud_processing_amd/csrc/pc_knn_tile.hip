@@ -363,6 +363,23 @@ __global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__
     }
 }
 
+// The same from the flags' side, for searches that hold a map from original index to output row (the compact
+// outputs of a query range: row = sorted position - s_begin): the flags are read in order and only the open
+// points look anything up, where the walk over the records above reads a flag at a random place for every record
+// (66 M voxels, 2.2 M of them open: 7.2 -> 0.5 ms).
+__global__ __launch_bounds__(256) void k_collect_flagged_by_id(const uint8_t *__restrict__ qflag, const float *__restrict__ qub,
+                                                                const int32_t *__restrict__ slot, int64_t npt, int64_t s_begin,
+                                                                int32_t *__restrict__ list, float *__restrict__ ub,
+                                                                uint32_t *__restrict__ count, uint32_t cap) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npt || !qflag[i]) return;
+    const uint32_t p = atomicAdd(count, 1u);
+    if (p < cap) {
+        list[p] = (int32_t)(s_begin + slot[i]);
+        ub[p] = qub[i];
+    }
+}
+
 }  // namespace
 
 int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hipStream_t st, bool *handled) {
@@ -714,7 +731,10 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.qci = qci0;
         const unsigned nb = (unsigned)((A.nq + 255) / 256);
         const void *qsrc = A.qrec ? A.qrec : g->rec;  // (external queries: positions in the level-0 bins)
-        if (g->dtype == PC_F32)
+        if (!A.qrec && A.out_slot && A.compact_base < 0)
+            hipLaunchKernelGGL(k_collect_flagged_by_id, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, st, qflag, A.qub_arr,
+                               A.out_slot, (int64_t)npt, A.s_begin, A.flag_list, A.flag_ub, A.flag_count, A.flag_cap);
+        else if (g->dtype == PC_F32)
             hipLaunchKernelGGL(k_collect_flagged<Rec32>, dim3(nb), dim3(256), 0, st, (const Rec32 *)qsrc, A.s_begin,
                                A.s_end, qflag, A.qub_arr, A.flag_list, A.flag_ub, A.flag_count, A.flag_cap);
         else
