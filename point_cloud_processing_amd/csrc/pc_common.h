@@ -39,6 +39,8 @@ struct PcKnobs {
     int64_t mixed_min = 1ll << 20; // PC_AMD_MIXED_MIN
     uint32_t full_tile = 32;       // PC_AMD_FULL_TILE
     bool no_finer = false;         // PC_AMD_NO_FINER
+    bool no_ring = false;          // PC_AMD_NO_RING: no lane-per-query ring pass before the wave-per-query kernel (A/B switch)
+    int64_t ring_min = 4096;       // PC_AMD_RING_MIN: open queries from which that pass is worth its list
     bool no_bucket_build = false;  // PC_AMD_NO_BUCKET_BUILD: always the general index build (A/B switch)
 };
 PcKnobs pc_read_knobs();

@@ -97,6 +97,8 @@ PcKnobs pc_read_knobs() {
         k.full_tile = (uint32_t)num("PC_AMD_FULL_TILE", 32);
         k.no_finer = on("PC_AMD_NO_FINER");
         k.no_bucket_build = on("PC_AMD_NO_BUCKET_BUILD");
+        k.no_ring = on("PC_AMD_NO_RING");
+        k.ring_min = num("PC_AMD_RING_MIN", 4096);
         return k;
     }
 }

@@ -405,35 +405,47 @@ __device__ inline int64_t out_row_of(const ScanArgs &A, int64_t id, int64_t spos
 template <int MODE, bool ONLY_NORMALS = false, typename NB>
 __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, NB nb) {
     const int k = A.k;
-    if (!ONLY_NORMALS && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
-        for (int s = 0; s < k; s++) {
-            int32_t id = -1;
-            double d = INFINITY, x, y, z;
-            if (s < cnt) nb(s, d, x, y, z, id);
-            if (A.out_idx) A.out_idx[out_row * k + s] = id;
-            if (A.out_d2) {
-                if (A.d2_f64)
-                    reinterpret_cast<double *>(A.out_d2)[out_row * k + s] = d;
-                else
-                    reinterpret_cast<float *>(A.out_d2)[out_row * k + s] = (float)d;
+    const bool rows = !ONLY_NORMALS && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt);
+    const bool mean = !ONLY_NORMALS && (MODE == M_SOR || (MODE == M_ALL && A.out_f64));
+    const bool normal = MODE == M_NORMALS || (MODE == M_ALL && A.out_nrm);
+    // One walk over the neighbours feeds every consumer, and four neighbours are fetched before any of them is used:
+    // a neighbour may be a record in global memory (fp64 grids), and a walk per consumer with one record in
+    // flight waited for 3 k round trips per query (66 M voxels, k = 32, rows + mean distance + normals: 20 of
+    // the first tile pass's 58 ms).  Every sum still takes its terms nearest first, one by one.
+    constexpr int AT_ONCE = 4;
+    double sum = 0.0;
+    double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int upto = rows ? k : ((mean || (normal && cnt >= 3)) ? cnt : 0);
+    for (int s0 = 0; s0 < upto; s0 += AT_ONCE) {
+        double d[AT_ONCE], x[AT_ONCE], y[AT_ONCE], z[AT_ONCE];
+        int32_t id[AT_ONCE];
+#pragma unroll
+        for (int v = 0; v < AT_ONCE; v++) {
+            id[v] = -1;
+            d[v] = INFINITY;
+            x[v] = y[v] = z[v] = 0.0;
+            if (s0 + v < cnt) nb(s0 + v, d[v], x[v], y[v], z[v], id[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < AT_ONCE; v++) {
+            const int s = s0 + v;
+            if (rows && s < k) {
+                if (A.out_idx) A.out_idx[out_row * k + s] = id[v];
+                if (A.out_d2) {
+                    if (A.d2_f64)
+                        reinterpret_cast<double *>(A.out_d2)[out_row * k + s] = d[v];
+                    else
+                        reinterpret_cast<float *>(A.out_d2)[out_row * k + s] = (float)d[v];
+                }
+            }
+            if (s < cnt) {
+                if (mean) sum += sqrt(d[v]);
+                if (normal && cnt >= 3) cumulant_add(cu, x[v], y[v], z[v]);
             }
         }
-        if (A.out_cnt) A.out_cnt[out_row] = cnt;
     }
-    if (!ONLY_NORMALS && (MODE == M_SOR || (MODE == M_ALL && A.out_f64))) {
-        double m = -1.0;
-        if (cnt > 0) {
-            double sum = 0.0;
-            for (int s = 0; s < cnt; s++) {
-                double d, x, y, z;
-                int32_t id;
-                nb(s, d, x, y, z, id);
-                sum += sqrt(d);
-            }
-            m = sum / (double)cnt;
-        }
-        A.out_f64[out_row] = m;
-    }
+    if (rows && A.out_cnt) A.out_cnt[out_row] = cnt;
+    if (mean) A.out_f64[out_row] = cnt > 0 ? sum / (double)cnt : -1.0;
     if (!ONLY_NORMALS && MODE == M_NNDIST) {
         double d = 0.0, x, y, z;
         int32_t id;
@@ -443,18 +455,7 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
         }
         A.out_f64[out_row] = d;
     }
-    if (MODE == M_NORMALS || (MODE == M_ALL && A.out_nrm)) {
-        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (cnt >= 3) {
-            for (int s = 0; s < cnt; s++) {
-                double d, px, py, pz;
-                int32_t id;
-                nb(s, d, px, py, pz, id);
-                cumulant_add(cu, px, py, pz);
-            }
-        }
-        emit_normal<MODE>(A, out_row, cnt, cu);
-    }
+    if (normal) emit_normal<MODE>(A, out_row, cnt, cu);
 }
 
 // pc_knn_tile.hip: the tile-cooperative fast path (self-queries, k <= 50).
@@ -471,6 +472,10 @@ int pc_batch_open_list(pc_ctx *ctx, int dtype, const void *qsrc, int64_t n, cons
                        int64_t *count, int64_t *open_all, uint32_t *counter, hipStream_t st);
 int pc_launch_batch_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
                          hipStream_t st);
+
+// pc_knn_ring.hip: the open queries a ladder leaves, lane per query on the finest level with rings of several cells
+int pc_launch_ring_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
+                        uint32_t *answered, hipStream_t st);
 
 // pc_knn_wave.hip: one wave per listed query (A.qlist / A.qub / A.qcount).
 int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A, hipStream_t st);

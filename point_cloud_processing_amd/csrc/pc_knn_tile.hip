@@ -753,6 +753,33 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             if (!progress || open < std::max<int64_t>(2048, A.nq / 200)) break;
         }
     }
+    // What the ladder leaves open in numbers is next to something dense: too few candidates on the fine levels,
+    // too many for a tile on the coarse ones.  Those go, lane per query, through rings of the finest level cut to
+    // the ball of their bound (pc_knn_ring.hip) before a whole wave is spent on each of the rest.  (66 M voxels of
+    // planes + clutter, 2.19 M open: 44.6 ms of wave-per-query work.)
+    if (qflag && !qrec0 && A.radius2 < 0.0 && ks <= 34 && batch_passes && !knobs.no_ring && open_prev >= knobs.ring_min) {
+        A.gp = g->gp;
+        A.rec = g->rec;
+        A.ci = g->index();
+        A.qrec = nullptr;
+        A.qflag_in = qflag;
+        A.qflag_out = qflag;
+        int64_t nopen = 0, all = 0;
+        PC_TRY(pc_batch_open_list(ctx, g->dtype, g->rec, g->n, qflag, 255, open_list, &nopen, &all, open_counter, st));
+        uint32_t *answered = knobs.debug ? A.flag_count + 30 : nullptr;
+        PC_TRY(pc_launch_ring_scan(ctx, g->dtype, ks, mode, A, open_list, nopen, answered, st));
+        if (knobs.debug) {
+            uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pinned);
+            PC_HIP(hipMemcpyAsync(h, answered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PC_HIP(hipStreamSynchronize(st));
+            fprintf(stderr, "[pc_amd]   ring pass: %lld open queries, %u answered\n", (long long)nopen, h[0]);
+            PC_HIP(hipMemcpyAsync(h, A.flag_count + 40, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PC_HIP(hipStreamSynchronize(st));
+            if (h[7])
+                fprintf(stderr, "[pc_amd]   ring pass per wave: %.1f iterations, %.1f insertion rounds; per query: %.1f picks, %.1f rows, %.1f candidates\n",
+                        (double)h[0] / h[7], (double)h[4] / h[7], (double)h[1] / nopen, (double)h[2] / nopen, (double)h[3] / nopen);
+        }
+    }
     if (qflag) {
         // back to level 0: the re-run lists hold level-0 sorted positions
         A.gp = g->gp;
