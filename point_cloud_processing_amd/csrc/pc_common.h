@@ -21,7 +21,8 @@ struct PcKnobs {
     bool debug = false;            // PC_AMD_DEBUG: per-pass log on stderr
     double cell_scale = 0.0;       // PC_AMD_CELL_SCALE: scales the automatic cell edge (0: off)
     bool no_halves = false;        // PC_AMD_NO_HALVES
-    int eager_levels = 0;          // PC_AMD_EAGER_LEVELS: levels built with the index (0: EAGER_LEVELS)
+    int eager_levels = 0;          // PC_AMD_EAGER_LEVELS: levels built with the index (0: EAGER_LEVELS, or 1 from lazy_min points on)
+    int64_t lazy_min = 1ll << 20;  // PC_AMD_LAZY_MIN: clouds of this size and more build the finest level only; searches make the levels worth a pass
     int lazy_div = 0;              // PC_AMD_LAZY_DIV: a further level is made while more than n / this many queries are open (0: default)
     int max_levels = 0;            // PC_AMD_MAX_LEVELS: levels of a multi-level index at most (0: MAX_LEVELS)
     double seed_scale = 0.0;       // PC_AMD_SEED_SCALE: the tile kernel's starting threshold over the certification bound (0: default)
@@ -39,6 +40,7 @@ struct PcKnobs {
     int64_t mixed_min = 1ll << 20; // PC_AMD_MIXED_MIN
     uint32_t full_tile = 32;       // PC_AMD_FULL_TILE
     bool no_finer = false;         // PC_AMD_NO_FINER
+    bool no_postpone = false;      // PC_AMD_NO_POSTPONE: sparse tiles' queries are not postponed tile by tile before the first list pass (A/B switch)
     bool no_ring = false;          // PC_AMD_NO_RING: no lane-per-query ring pass before the wave-per-query kernel (A/B switch)
     int64_t ring_min = 4096;       // PC_AMD_RING_MIN: open queries from which that pass is worth its list
     bool no_bucket_build = false;  // PC_AMD_NO_BUCKET_BUILD: always the general index build (A/B switch)
@@ -220,6 +222,9 @@ int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid *
 // the next coarser level of a multi-level index (cells of twice the edge; kept in g->coarse); *out = NULL where there
 // is none to make (MAX_LEVELS reached, or the grid is down to four cells an axis)
 int pc_grid_coarser(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid **out);
+// level `level` of a multi-level index (cells 2^level times the finest's), made from the records of `last`, the coarsest
+// level there is, and hung behind it: levels in between are left out; *out = NULL where there is none to make
+int pc_grid_level(pc_ctx *ctx, const pc_grid *last, int level, hipStream_t st, const pc_grid **out);
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
                    hipStream_t st);
 

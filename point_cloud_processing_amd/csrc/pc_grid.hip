@@ -98,6 +98,8 @@ PcKnobs pc_read_knobs() {
         k.no_finer = on("PC_AMD_NO_FINER");
         k.no_bucket_build = on("PC_AMD_NO_BUCKET_BUILD");
         k.no_ring = on("PC_AMD_NO_RING");
+        k.no_postpone = on("PC_AMD_NO_POSTPONE");
+        k.lazy_min = num("PC_AMD_LAZY_MIN", 1ll << 20);
         k.ring_min = num("PC_AMD_RING_MIN", 4096);
         return k;
     }
@@ -1129,7 +1131,10 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         // clouds never look at levels 5 to 8, and sorting all points four more times was a fifth to a third of
         // their build: 2 M sphere 1.37 -> 1.0 ms, LiDAR frame 0.95 -> 0.73 ms, 13 M voxels of planes + clutter
         // 7.6 -> 5.4 ms, with the searches as fast or faster.)
-        const int eager = ctx->knobs.eager_levels >= 2 ? std::min(ctx->knobs.eager_levels, MAX_LEVELS) : EAGER_LEVELS;
+        // (Big clouds get the finest level only: their searches look at what the first pass leaves open and make
+        // just the levels worth a pass -- 66 M voxels of planes + clutter visit levels 0 and 2 of four.)
+        const int eager = ctx->knobs.eager_levels >= 1 ? std::min(ctx->knobs.eager_levels, MAX_LEVELS)
+                                                        : (n >= ctx->knobs.lazy_min ? 1 : EAGER_LEVELS);
         const int max_lv = ctx->knobs.max_levels > 0 ? std::min(ctx->knobs.max_levels, MAX_LEVELS) : eager;
         for (int lv = 1; lv < max_lv; lv++) {
             if (std::max(fine->gp.dim[0], std::max(fine->gp.dim[1], fine->gp.dim[2])) <= 4) break;
@@ -1183,6 +1188,24 @@ int pc_grid_coarser(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid
     c->uneven = true;
     c->level = g->level + 1;
     g->coarse = c;
+    *out = c;
+    return PC_OK;
+}
+
+int pc_grid_level(pc_ctx *ctx, const pc_grid *last, int level, hipStream_t st, const pc_grid **out) {
+    *out = nullptr;
+    if (last->coarse || !last->uneven || last->n <= 0 || last->level < 0 || level <= last->level || level >= MAX_LEVELS ||
+        (ctx->knobs.max_levels > 0 && level >= ctx->knobs.max_levels))
+        return PC_OK;
+    // (like pc_grid_coarser level by level: none beyond a level that is down to four cells an axis)
+    int d = std::max(last->gp.dim[0], std::max(last->gp.dim[1], last->gp.dim[2]));
+    for (int v = last->level; v < level - 1; v++) d = d / 2 + 1;
+    if (d <= 4) return PC_OK;
+    pc_grid *c = nullptr;
+    PC_TRY(grid_build_impl(ctx, nullptr, last->dtype, last->n, ldexp(last->gp.cell, level - last->level), 0, &c, (void *)st, last));
+    c->uneven = true;
+    c->level = level;
+    last->coarse = c;
     *out = c;
     return PC_OK;
 }

@@ -192,10 +192,11 @@ __global__ __launch_bounds__(PC_WAVE) void k_batch_scan(ScanArgs A, const int32_
     drain();
     if (!active) return;
     if (crowded) {
-        if (!A.qflag_in) {  // first pass: flags and bounds are not initialised yet
+        if (!A.qflag_in) A.qub_arr[qid] = INFINITY;  // first pass: flags and bounds are not initialised yet
+        if (A.flag_top > 0)
+            A.qflag_out[qid] = FLAG_CROWDED;  // (coarser cells are fuller still: no later level lists it)
+        else if (!A.qflag_in)
             A.qflag_out[qid] = 1;
-            A.qub_arr[qid] = INFINITY;
-        }
         return;
     }
 

@@ -154,6 +154,11 @@ struct ScanArgs {
     double seed_scale;
 };
 
+// The flag of an open query amid more candidates than any level's pass stages (only where passes may postpone
+// queries, ScanArgs::flag_top > 0): coarser cells hold more candidates still, so no later level lists it; it waits
+// for the passes over ALL open queries (finer grids, rings of the finest level, one wave per query).
+constexpr uint8_t FLAG_CROWDED = 200;
+
 // an open query (flag set) that the pass of flag_max answers
 __host__ __device__ inline bool flag_live(uint8_t flag, int flag_max) { return flag != 0 && (int)flag <= flag_max; }
 

@@ -270,14 +270,14 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
         };
         const uint32_t a = wsum(st_pick), b = wsum(st_rows), cnd = wsum(st_cand), sm = wsum(st_samp);
         if (lane == 0) {
-            atomicAdd(A.flag_count + 40, st_iter);    // outer iterations (per wave)
-            atomicAdd(A.flag_count + 41, a);          // picks (lanes)
-            atomicAdd(A.flag_count + 42, b);          // rows looked at (lanes)
-            atomicAdd(A.flag_count + 43, cnd);        // candidates measured (lanes)
-            atomicAdd(A.flag_count + 44, st_drain);   // insertion rounds (per wave)
-            atomicAdd(A.flag_count + 45, sm);         // samples (lanes)
-            atomicAdd(A.flag_count + 46, st_sbatch);  // sample batches (per wave)
-            atomicAdd(A.flag_count + 47, 1u);
+            atomicAdd(A.flag_count + 48, st_iter);    // outer iterations (per wave)
+            atomicAdd(A.flag_count + 49, a);          // picks (lanes)
+            atomicAdd(A.flag_count + 50, b);          // rows looked at (lanes)
+            atomicAdd(A.flag_count + 51, cnd);        // candidates measured (lanes)
+            atomicAdd(A.flag_count + 52, st_drain);   // insertion rounds (per wave)
+            atomicAdd(A.flag_count + 53, sm);         // samples (lanes)
+            atomicAdd(A.flag_count + 54, st_sbatch);  // sample batches (per wave)
+            atomicAdd(A.flag_count + 55, 1u);
         }
     }
 #endif

@@ -210,6 +210,52 @@ __global__ __launch_bounds__(256) void k_open_range(const REC *__restrict__ rec,
     qub[id] = INFINITY;
 }
 
+// The open queries of the listed tiles whose block -- the tile and a cell around it, a superset of every member's
+// 27 cells -- holds fewer than 2 k points are postponed like the list kernel would postpone them one by one (too few
+// candidates to find k of them within reach; the flag names the first level whose cells, eight times the volume each,
+// promise 4 k), without a look at the queries themselves: one thread per tile, sixteen row look-ups, a flag per point.
+// (66 M voxels of planes + clutter: 29.6 M of the 30.8 M queries the first list pass looked up, 21 ms for 1.2 M answers.)
+template <typename REC>
+__global__ __launch_bounds__(256) void k_tile_postpone(GridParams gp, CellIndex ci, const REC *__restrict__ rec, int tx, int ty,
+                                                        int tz, int ntx, int nty, const uint32_t *__restrict__ tiles, int64_t m,
+                                                        int k, int flag_max, int flag_top, int64_t s_begin, int64_t s_end,
+                                                        uint8_t *__restrict__ qflag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int64_t t = tiles[i];
+    const int x0 = (int)(t % ntx) * tx, y0 = (int)((t / ntx) % nty) * ty, z0 = (int)(t / ((int64_t)ntx * nty)) * tz;
+    const int x1 = min(x0 + tx, gp.dim[0]), y1 = min(y0 + ty, gp.dim[1]), z1 = min(z0 + tz, gp.dim[2]);
+    const int bx0 = max(x0 - 1, 0), bx1 = min(x1 + 1, gp.dim[0]);
+    uint32_t pop = 0;
+    for (int z = max(z0 - 1, 0); z < min(z1 + 1, gp.dim[2]); z++)
+        for (int y = max(y0 - 1, 0); y < min(y1 + 1, gp.dim[1]); y++) {
+            const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+            uint32_t b, e;
+            cell_range(ci, row + bx0, row + bx1, b, e);
+            pop += e - b;
+        }
+    if (pop >= 2u * (uint32_t)k) return;
+    // (a member's 27 cells hold about 27 / 64 of the block's points: the growth is reckoned from that)
+    uint32_t pred = max((pop * 27u + 63u) / 64u, 1u) * 8u;
+    int f = flag_max + 1;
+    while (pred < 4u * (uint32_t)k && f < flag_top) {
+        pred *= 8u;
+        f++;
+    }
+    for (int z = z0; z < z1; z++)
+        for (int y = y0; y < y1; y++) {
+            const int64_t row = ((int64_t)z * gp.dim[1] + y) * gp.dim[0];
+            uint32_t b, e;
+            cell_range(ci, row + x0, row + x1, b, e);
+            for (uint32_t j = max((int64_t)b, s_begin); j < min((int64_t)e, s_end); j++) {
+                double px, py, pz;
+                int32_t id;
+                RecTraits<REC>::load(rec + j, px, py, pz, id);
+                if (qflag[id] == 1) qflag[id] = (uint8_t)f;
+            }
+        }
+}
+
 }  // namespace
 
 void pc_dense_tile_shape(const pc_ctx *ctx, double occ, const int32_t dim[3], int best[3], int *waves_out, double *pop_out) {
@@ -366,6 +412,42 @@ __global__ __launch_bounds__(256) void k_collect_flagged(const REC *__restrict__
 // The same from the flags' side, for searches that hold a map from original index to output row (the compact
 // outputs of a query range: row = sorted position - s_begin): the flags are read in order and only the open
 // points look anything up, where the walk over the records above reads a flag at a random place for every record.
+// counts[f] = points whose flag is f (f < 15), counts[15] = points with any larger flag (FLAG_CROWDED)
+__global__ __launch_bounds__(256) void k_flag_hist(const uint8_t *__restrict__ qflag, int64_t npt, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) mine[b] = 0;
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (base + 16 <= npt && (reinterpret_cast<uintptr_t>(qflag) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(qflag + base);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t f = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+#pragma unroll
+            for (int b = 1; b < 16; b++) mine[b] += (b < 15 ? f == (uint32_t)b : f >= 15u) ? 1u : 0u;
+        }
+    } else {
+        for (int i = 0; i < 16 && base + i < npt; i++) {
+            const uint32_t f = qflag[base + i];
+#pragma unroll
+            for (int b = 1; b < 16; b++) mine[b] += (b < 15 ? f == (uint32_t)b : f >= 15u) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int b = 1; b < 16; b++) {
+        uint32_t v = mine[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[b], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && threadIdx.x > 0 && h[threadIdx.x]) atomicAdd(counts + threadIdx.x, h[threadIdx.x]);
+}
+
 constexpr int COLLECT_PER_THREAD = 16;
 __global__ __launch_bounds__(256) void k_collect_flagged_by_id(const uint8_t *__restrict__ qflag, const float *__restrict__ qub,
                                                                 const int32_t *__restrict__ slot, int64_t npt, int64_t s_begin,
@@ -437,7 +519,10 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     // block returns to the pool when this function ends, which is safe because everything that
     // touches it is ordered on `st`
     const size_t npt = A.qrec ? (size_t)A.nq : (size_t)pc_index_space(g);  // per-point arrays are indexed by original index
-    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (nlv > 1 ? 9 * npt + 128 : 0));
+    // (the per-point arrays of a ladder of levels: also where a big cloud comes with its finest level only and the
+    // search makes the others)
+    const bool ladder = nlv > 1 || (g->uneven && g->n >= ctx->knobs.lazy_min && ctx->knobs.eager_levels == 0);
+    Scratch flags(ctx, 3 * sizeof(int32_t) * (size_t)A.nq + 256 + (ladder ? 9 * npt + 128 : 0));
     if (!flags.ok()) return pc_fail(ctx, PC_NOMEM, "re-run lists");
     A.flag_count = flags.as<uint32_t>();
     A.flag2_count = A.flag_count + 16;
@@ -447,7 +532,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     PC_HIP(hipMemsetAsync(A.flag_count, 0, 256, st));
     uint8_t *qflag = nullptr;
     int32_t *open_list = nullptr;
-    if (nlv > 1) {
+    if (ladder) {
         A.qub_arr = reinterpret_cast<float *>(A.flag2_list + A.nq);
         open_list = reinterpret_cast<int32_t *>(A.qub_arr + npt);
         qflag = reinterpret_cast<uint8_t *>(open_list + npt);
@@ -467,7 +552,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     const void *qrec0 = A.qrec;
     const CellIndex qci0 = A.qci;
     const size_t qrec_bytes = (g->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64)) * (size_t)A.nq;
-    Scratch qrec_l(ctx, A.qrec && nlv > 1 ? qrec_bytes : 0), qkeys_l(ctx, A.qrec && nlv > 1 ? sizeof(uint32_t) * (size_t)A.nq : 0);
+    Scratch qrec_l(ctx, A.qrec && ladder ? qrec_bytes : 0), qkeys_l(ctx, A.qrec && ladder ? sizeof(uint32_t) * (size_t)A.nq : 0);
     if (!qrec_l.ok() || !qkeys_l.ok()) return pc_fail(ctx, PC_NOMEM, "query records");
     // Postponed queries (self-queries of k-nearest searches on multi-level indexes): a list pass that finds
     // far too few candidates around a query names, in the query's flag, the first level worth trying again,
@@ -482,6 +567,8 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
              d > 4 && nlv_possible < MAX_LEVELS && !(knobs.max_levels > 0 && nlv_possible >= knobs.max_levels); d = d / 2 + 1)
             nlv_possible++;
     A.flag_top = hinted ? nlv_possible : 0;
+    // (a big cloud comes with its finest level only; the levels worth a pass are made as the flags ask for them)
+    const bool lazy = hinted && nlv == 1 && g->uneven && g->n >= knobs.lazy_min && knobs.eager_levels == 0;
     uint32_t *open_counter = A.flag_count + 29;  // (24..28: counters of instrumented builds)
     int64_t open_all = 0;
     for (int i = 0; i < nlv; i++) {
@@ -526,7 +613,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
         A.halves = l->halves && !l->uneven && g->dtype == PC_F32 ? 1 : 0;
         A.qflag_in = i == 0 ? nullptr : qflag;
         A.qflag_out = qflag;  // NULL with a single level: uncertified queries go straight to the list
-        A.flag_max = hinted ? i + 1 : 255;
+        A.flag_max = hinted ? l->level + 1 : 255;
         A.count_crowded = i == 0;
         // First pass of an uneven cloud that the list kernel would take: where the cloud is dense (surfaces
         // in a sea of clutter) whole tiles are full of queries that share one candidate block, which is the
@@ -597,6 +684,18 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.tile_list = l->tile_list;
             A.cand_cap = l->tile_cap;
             A.count_crowded = 1;
+            if (hinted && A.flag_top > A.flag_max && !knobs.no_postpone) {
+                const unsigned nbt = (unsigned)((l->tile_count + 255) / 256);
+                if (g->dtype == PC_F32)
+                    hipLaunchKernelGGL(k_tile_postpone<Rec32>, dim3(nbt), dim3(256), 0, st, l->gp, l->index(), (const Rec32 *)l->rec, l->tile[0],
+                                       l->tile[1], l->tile[2], A.ntile[0], A.ntile[1], l->tile_list, l->tile_count, A.k, A.flag_max,
+                                       A.flag_top, A.s_begin, A.s_end, qflag);
+                else
+                    hipLaunchKernelGGL(k_tile_postpone<Rec64>, dim3(nbt), dim3(256), 0, st, l->gp, l->index(), (const Rec64 *)l->rec, l->tile[0],
+                                       l->tile[1], l->tile[2], A.ntile[0], A.ntile[1], l->tile_list, l->tile_count, A.k, A.flag_max,
+                                       A.flag_top, A.s_begin, A.s_end, qflag);
+                PC_HIP(hipGetLastError());
+            }
             int64_t nopen = 0;
             PC_TRY(pc_batch_open_list(ctx, g->dtype, l->rec, l->n, qflag, A.flag_max, open_list, &nopen, &open_all, open_counter, st));
             if (knobs.debug) fprintf(stderr, "[pc_amd]   batch pass 0: %lld open queries\n", (long long)nopen);
@@ -666,7 +765,38 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             // list: one read-back per level either way)
             int64_t open = 0;
             bool counted = false;
-            if (i + 1 == nlv && nlv < MAX_LEVELS && g->uneven) {
+            if (i + 1 == nlv && nlv < MAX_LEVELS && g->uneven && lazy) {
+                // The last level there is, of a big cloud that was given its finest level only: the flags say which
+                // level is worth making next.  A postponed query names the level that is to list it; a level whose
+                // list would hold under a sixteenth of the queries still waiting for some level is left out (its
+                // queries ride on to the next one), and queries amid more candidates than a pass stages wait for no
+                // level at all.  (66 M voxels of planes + clutter: levels 1 and 3 would answer 0.15 M and 0.04 M
+                // queries of 29.6 M and 2.2 M open ones -- 8 ms of passes and 9 ms of sorting the cloud twice.)
+                uint32_t *hc = A.flag_count + 32;  // (words 32..47 of the counter block)
+                PC_HIP(hipMemsetAsync(hc, 0, 16 * sizeof(uint32_t), st));
+                hipLaunchKernelGGL(k_flag_hist, dim3((unsigned)((npt + 4095) / 4096)), dim3(256), 0, st, qflag, (int64_t)npt, hc);
+                uint32_t *hh = reinterpret_cast<uint32_t *>(ctx->pinned);
+                PC_HIP(hipMemcpyAsync(hh, hc, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                PC_HIP(hipStreamSynchronize(st));
+                int64_t waiting = 0;
+                for (int f = 1; f < 15; f++) waiting += hh[f];
+                open = waiting + hh[15];
+                counted = true;
+                if (waiting >= std::max<int64_t>(2048, A.nq / 200)) {
+                    int v = l->level + 1;
+                    for (; v < MAX_LEVELS; v++) {
+                        int64_t listed = 0;
+                        for (int f = 1; f <= std::min(v + 1, 14); f++) listed += hh[f];
+                        if (listed >= std::max<int64_t>(2048, waiting / 16)) break;
+                    }
+                    const pc_grid *more = nullptr;
+                    if (v < MAX_LEVELS) PC_TRY(pc_grid_level(ctx, lv[i], v, st, &more));
+                    if (more) lv[nlv++] = more;
+                    if (knobs.debug)
+                        fprintf(stderr, "[pc_amd]   %lld waiting for a level, %u crowded: level %d %s\n", (long long)waiting, hh[15], v,
+                                more ? "made" : "not made");
+                }
+            } else if (i + 1 == nlv && nlv < MAX_LEVELS && g->uneven) {
                 // the last level there is: the next one is made only if enough queries are still open for the
                 // ladder to go on (one more count read back, at this level only)
                 PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
@@ -691,7 +821,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                     binned_level = i + 1;
                 }
                 PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : nl->rec, qrec0 ? A.nq : nl->n, qflag,
-                                          hinted ? i + 2 : 255, open_list, &list_count, &open, open_counter, st));
+                                          hinted ? nl->level + 1 : 255, open_list, &list_count, &open, open_counter, st));
                 list_level = i + 1;  // (listed: the queries the next level is to try; open: those and the ones that wait for a later one)
             } else if (!counted) {
                 PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
@@ -773,7 +903,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             PC_HIP(hipMemcpyAsync(h, answered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             PC_HIP(hipStreamSynchronize(st));
             fprintf(stderr, "[pc_amd]   ring pass: %lld open queries, %u answered\n", (long long)nopen, h[0]);
-            PC_HIP(hipMemcpyAsync(h, A.flag_count + 40, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PC_HIP(hipMemcpyAsync(h, A.flag_count + 48, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             PC_HIP(hipStreamSynchronize(st));
             if (h[7])
                 fprintf(stderr, "[pc_amd]   ring pass per wave: %.1f iterations, %.1f insertion rounds; per query: %.1f picks, %.1f rows, %.1f candidates\n",

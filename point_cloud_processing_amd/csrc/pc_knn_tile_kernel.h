@@ -230,7 +230,9 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
     q_off -= q_cnt;
     const bool too_many = ncand > (uint32_t)A.cand_cap;
     const bool splittable = may_split && (ext[0] > 1 || ext[1] > 1 || ext[2] > 1);
-    if (A.qflag_in && too_many && !splittable) return 0;  // flagged points of an over-full block stay flagged
+    // flagged points of an over-full block stay flagged (where passes may postpone queries, they are re-flagged as
+    // crowded below, so that no coarser level lists them again)
+    if (A.qflag_in && too_many && !splittable && A.flag_top == 0) return 0;
     if (too_many && splittable) return 1;                 // (before looking for flagged points: a coarse tile holds millions)
     if (A.qflag_in) {
         // later passes answer only the points an earlier pass flagged: leave if the tile has none
@@ -415,7 +417,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             }
             if (live) {
                 if (A.qflag_out) {
-                    A.qflag_out[qid] = 1;
+                    A.qflag_out[qid] = too_many && A.flag_top > 0 ? FLAG_CROWDED : (uint8_t)1;
                     if (!A.qflag_in) A.qub_arr[qid] = INFINITY;
                 } else {
                     const uint32_t p = atomicAdd(A.flag_count, 1u);

@@ -1,6 +1,9 @@
-"""The lane-per-query ring pass over what a multi-level ladder leaves open (csrc/pc_knn_ring.hip) against the
-wave-per-query kernel that answers those queries without it: the same rows, distances and normals, bit for bit,
-and both equal to the CPU oracle."""
+"""Routes through a multi-level index that only big clouds take by themselves, forced on small ones: the
+lane-per-query ring pass over what the ladder leaves open (csrc/pc_knn_ring.hip) against the wave-per-query kernel
+that answers those queries without it, and the ladder of a cloud that comes with its finest level only (levels made
+as the flags of the postponed queries ask for them, sparse tiles postponed tile by tile, full tiles first) against
+the ladder over levels built with the index: the same rows, distances and normals, bit for bit, and equal to the
+CPU oracle."""
 import numpy as np
 import pytest
 
@@ -41,6 +44,43 @@ def engines():
             else:
                 os.environ[k] = v
     return ring, plain
+
+
+@pytest.fixture(scope="module")
+def lazy_engine():
+    """Big-cloud routes from the first point on: finest level only, full tiles first, tile-wise postponement, rings."""
+    import os
+    from point_cloud_processing_amd.hip_engine import HipEngine
+
+    forced = {"PC_AMD_LAZY_MIN": "1", "PC_AMD_MIXED_MIN": "1", "PC_AMD_RING_MIN": "1"}
+    old = {k: os.environ.get(k) for k in forced}
+    try:
+        os.environ.update(forced)
+        eng = HipEngine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return eng
+
+
+@pytest.mark.parametrize("name", list(_clouds()))
+def test_levels_made_on_demand_equal_levels_built_with_the_index(engines, lazy_engine, name):
+    _, plain = engines
+    pts, k = _clouds()[name]
+    a = lazy_engine.knn(pts, None, k, -1.0, {})
+    b = plain.knn(pts, None, k, -1.0, {})
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    fa = lazy_engine.knn_fused(pts, k, -1.0, {})
+    fb = plain.knn_fused(pts, k, -1.0, {})
+    assert all(np.array_equal(x, y) for x, y in zip(fa, fb))
+    # a hybrid search (radius + k) takes the ladder without postponed queries
+    r = float(np.sqrt(np.median(b[1][:, min(k, 8) - 1]))) * 1.5
+    ha = lazy_engine.knn(pts, None, k, r, {})
+    hb = plain.knn(pts, None, k, r, {})
+    assert all(np.array_equal(x, y) for x, y in zip(ha, hb))
 
 
 @pytest.mark.parametrize("name", list(_clouds()))
