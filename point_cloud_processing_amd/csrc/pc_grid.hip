@@ -98,6 +98,8 @@ PcKnobs pc_read_knobs() {
         k.no_finer = on("PC_AMD_NO_FINER");
         k.no_bucket_build = on("PC_AMD_NO_BUCKET_BUILD");
         k.no_ring = on("PC_AMD_NO_RING");
+        k.no_probe = on("PC_AMD_NO_PROBE");
+        if (const char *e = getenv("PC_AMD_DENSE_FACTOR")) k.dense_factor = atof(e);
         k.no_postpone = on("PC_AMD_NO_POSTPONE");
         k.lazy_min = num("PC_AMD_LAZY_MIN", 1ll << 20);
         k.ring_min = num("PC_AMD_RING_MIN", 4096);
@@ -330,6 +332,12 @@ __global__ __launch_bounds__(256) void k_cell_keys32(const T *__restrict__ xyz, 
     if (halfbit) key = (key << 1) | x_half_of((double)xyz[3 * i], gp, (int)c[0]);
     keys[i] = key;
     vals[i] = (uint32_t)i;
+}
+
+// counts[cell] += 1 for every key, sorted or not (halfbit: the key's lowest bit is not part of the cell)
+__global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ counts, int halfbit) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(counts + (keys[i] >> halfbit), 1u);
 }
 
 // Per-cell counts from the SORTED keys, no searching: the last element of a run adds its end
@@ -901,6 +909,8 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             break;
         }
         bool in_tmp = false, dense = true, built_direct = false;
+        // (small clouds keep the table twice as long: the searches of a sparse grid's keys cost them more than the table)
+        const double dense_factor = ctx->knobs.dense_factor * (n < (1ll << 20) ? 2.0 : 1.0);
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
         // Where smaller cells separate nothing -- as many occupied cells as before: the crowd in a cell is copies
@@ -916,7 +926,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             g->gp.s = 1.0 / cell;
             g->ncell = (int64_t)g->gp.dim[0] * g->gp.dim[1] * g->gp.dim[2];
             // evenly filled fp32 clouds (decided later; the bit is harmless otherwise): x-halves inside the cells
-            dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
+            dense = (double)g->ncell <= dense_factor * (double)n + 4096.0;
             // (not for the nearly empty cells of k <= 2: nothing to gain from halving one or two points)
             const int halfbit = (!parent && automatic && dense && dtype == PC_F32 && g->ncell < (1ll << 31) && k_hint > 2 &&
                                  !ctx->knobs.no_halves) ? 1 : 0;
@@ -950,71 +960,87 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                         fprintf(stderr, "[pc_amd]   bucketed build: %s\n", built_direct ? "taken" : "a bucket or cell overflowed, general build");
                 }
             }
+            // A cloud given as an array whose cells are still to be settled is COUNTED into the cell table first (one
+            // atomic per point) and sorted only once the cell edge is accepted: an edge that is given up never pays
+            // for a sort (a LiDAR frame tries three edges).
+            bool probe = false;
+            auto sort_keys = [&]() {
+                return pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(), vals2.as<uint32_t>(), n,
+                                             bits_for((uint64_t)g->ncell - 1) + halfbit, st, &in_tmp);
+            };
             if (!built_direct) {
-            if (parent && dtype == PC_F32)
-                hipLaunchKernelGGL(k_cell_keys32_rec<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                                   (const Rec32 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
-            else if (parent)
-                hipLaunchKernelGGL(k_cell_keys32_rec<Rec64>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                                   (const Rec64 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
-            else if (dtype == PC_F32)
-                hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                                   (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), halfbit);
-            else
-                hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
-                                   (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), 0);
-            rc = pc_radix_sort_pairs32(ctx, keys.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint32_t>(),
-                                       vals2.as<uint32_t>(), n, bits_for((uint64_t)g->ncell - 1) + halfbit, st, &in_tmp);
-            if (rc) break;
-            const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
-            // per-cell counts (the offset table before its scan) while the table stays within 8 n + 4096
-            // cells; emptier grids keep the sorted keys instead and are searched
-            dense = (double)g->ncell <= 8.0 * (double)n + 4096.0;
-            if (g->cell_start) {
-                ctx->release(g->cell_start);
-                g->cell_start = nullptr;
-            }
-            if (dense) {
-                cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
-                g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
-                if (!g->cell_start) {
-                    rc = pc_fail(ctx, PC_NOMEM, "cell table");
+                if (parent && dtype == PC_F32)
+                    hipLaunchKernelGGL(k_cell_keys32_rec<Rec32>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                       (const Rec32 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+                else if (parent)
+                    hipLaunchKernelGGL(k_cell_keys32_rec<Rec64>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                       (const Rec64 *)parent->rec, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>());
+                else if (dtype == PC_F32)
+                    hipLaunchKernelGGL(k_cell_keys32<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                       (const float *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), halfbit);
+                else
+                    hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
+                                       (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), 0);
+                // per-cell counts (the offset table before its scan) while the table stays within 8 n + 4096
+                // cells; emptier grids keep the sorted keys instead and are searched
+                dense = (double)g->ncell <= dense_factor * (double)n + 4096.0;
+                // (small clouds only: their sorts are launch-bound; 66 M points on a first edge of 270 points per cell took
+                // 2 ms longer to count by atomics than to sort)
+                probe = automatic && !parent && dense && n < (1ll << 20) && !ctx->knobs.no_probe;
+                if (!probe) {
+                    rc = sort_keys();
+                    if (rc) break;
+                }
+                const uint32_t *sorted_keys = in_tmp ? keys2.as<uint32_t>() : keys.as<uint32_t>();
+                if (g->cell_start) {
+                    ctx->release(g->cell_start);
+                    g->cell_start = nullptr;
+                }
+                if (dense) {
+                    cs_bytes = sizeof(uint32_t) * (size_t)(g->ncell + 1);
+                    g->cell_start = (uint32_t *)ctx->alloc(cs_bytes);
+                    if (!g->cell_start) {
+                        rc = pc_fail(ctx, PC_NOMEM, "cell table");
+                        break;
+                    }
+                    if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
+                        rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell table");
+                        break;
+                    }
+                    if (probe)
+                        hipLaunchKernelGGL(k_cell_count, dim3(blocks_for(n, 256)), dim3(256), 0, st, keys.as<uint32_t>(), n, g->cell_start,
+                                           halfbit);
+                    else
+                        hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start,
+                                           halfbit);
+                }
+                // (a level made from another level has its cell edge given: nothing here waits for the numbers)
+                const bool defer = parent != nullptr && !automatic;
+                unsigned long long *sdev = stats.as<unsigned long long>();
+                if (defer) {
+                    g->stats_dev = (unsigned long long *)ctx->alloc(256);
+                    if (!g->stats_dev) {
+                        rc = pc_fail(ctx, PC_NOMEM, "grid statistics");
+                        break;
+                    }
+                    sdev = g->stats_dev;
+                }
+                if (hipMemsetAsync(sdev, 0, 2 * 8, st) != hipSuccess) break;
+                if (dense)
+                    hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 512u)), dim3(256), 0, st,
+                                       g->cell_start, g->ncell, sdev);
+                else
+                    hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st, sorted_keys,
+                                       n, sdev);
+                if (defer) {
+                    g->stats_pending = true;
                     break;
                 }
-                if (hipMemsetAsync(g->cell_start, 0, cs_bytes, st) != hipSuccess) {
-                    rc = pc_fail(ctx, PC_HIP_ERROR, "memset cell table");
+                if (hipMemcpyAsync(hs, stats.p, 2 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) {
+                    rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
                     break;
                 }
-                hipLaunchKernelGGL(k_cell_runs, dim3(blocks_for(n, 256)), dim3(256), 0, st, sorted_keys, n, g->cell_start,
-                                   halfbit);
-            }
-            // (a level made from another level has its cell edge given: nothing here waits for the numbers)
-            const bool defer = parent != nullptr && !automatic;
-            unsigned long long *sdev = stats.as<unsigned long long>();
-            if (defer) {
-                g->stats_dev = (unsigned long long *)ctx->alloc(256);
-                if (!g->stats_dev) {
-                    rc = pc_fail(ctx, PC_NOMEM, "grid statistics");
-                    break;
-                }
-                sdev = g->stats_dev;
-            }
-            if (hipMemsetAsync(sdev, 0, 2 * 8, st) != hipSuccess) break;
-            if (dense)
-                hipLaunchKernelGGL(k_count_stats, dim3(std::min(blocks_for(g->ncell, 256), 512u)), dim3(256), 0, st,
-                                   g->cell_start, g->ncell, sdev);
-            else
-                hipLaunchKernelGGL(k_run_stats, dim3(std::min(blocks_for(n, 256), 1024u)), dim3(256), 0, st, sorted_keys,
-                                   n, sdev);
-            if (defer) {
-                g->stats_pending = true;
-                break;
-            }
-            if (hipMemcpyAsync(hs, stats.p, 2 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) {
-                rc = pc_fail(ctx, PC_HIP_ERROR, "grid occupancy statistics");
-                break;
-            }
             }  // (general route)
             double seen = (double)hs[0] / (double)n;  // occupancy a random point sees (Poisson: mean + 1)
             g->occupied = (int64_t)hs[1];
@@ -1022,23 +1048,31 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             if (ctx->knobs.debug && automatic)
                 fprintf(stderr, "[pc_amd]   grid attempt %d: cell %.4g cells %lld occupied %lld seen %.1f (target %.1f)\n", attempt,
                         cell, (long long)g->ncell, (long long)g->occupied, seen, target);
-            if (!automatic || attempt >= 8 || settle) break;
-            if (seen <= 2.0 * (target + 1.0)) break;
-            if (attempt > 0 && g->occupied <= prev_occupied + prev_occupied / 50) {
+            bool accept = !automatic || attempt >= 8 || settle || seen <= 2.0 * (target + 1.0);
+            if (!accept && attempt > 0 && g->occupied <= prev_occupied + prev_occupied / 50) {
                 cell = prev_cell;
                 for (int a = 0; a < 3; a++) g->gp.dim[a] = prev_dim[a];
                 settle = true;
                 continue;
             }
-            prev_occupied = g->occupied;
-            prev_cell = cell;
-            for (int a = 0; a < 3; a++) prev_dim[a] = g->gp.dim[a];
-            int32_t dim2[3];
-            const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
-            const double got = fit_dims(want, dim2);
-            if (got > 0.93 * cell) break;  // the key range binds: no finer grid available
-            cell = got;
-            for (int a = 0; a < 3; a++) g->gp.dim[a] = dim2[a];
+            if (!accept) {
+                prev_occupied = g->occupied;
+                prev_cell = cell;
+                for (int a = 0; a < 3; a++) prev_dim[a] = g->gp.dim[a];
+                int32_t dim2[3];
+                const double want = cell * std::max(0.3, sqrt(1.15 * (target + 1.0) / seen));
+                const double got = fit_dims(want, dim2);
+                if (got > 0.93 * cell) {
+                    accept = true;  // the key range binds: no finer grid available
+                } else {
+                    cell = got;
+                    for (int a = 0; a < 3; a++) g->gp.dim[a] = dim2[a];
+                }
+            }
+            if (accept) {
+                if (probe) rc = sort_keys();  // (the edge stays: now the points are put in order)
+                break;
+            }
         }
         if (rc) break;
         g->gp.cell = cell;
