@@ -847,7 +847,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
         }
     }
     // u32 cell keys: below 2^32 cells.  A dense offset table is kept while it stays within
-    // 8 n + 4096 cells; emptier grids use the sparse index (binary search over the sorted keys).
+    // 16 n + 4096 cells; emptier grids use the sparse index (binary search over the sorted keys).
     auto fit_dims = [&](double c, int32_t dim[3]) {
         for (int it = 0;; it++) {
             double tot = 1.0;
@@ -909,8 +909,10 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
             break;
         }
         bool in_tmp = false, dense = true, built_direct = false;
-        // (small clouds keep the table twice as long: the searches of a sparse grid's keys cost them more than the table)
-        const double dense_factor = ctx->knobs.dense_factor * (n < (1ll << 20) ? 2.0 : 1.0);
+        // (A table of up to 16 cells per point: looking a cell up in it is two loads where the sorted keys of a table-less
+        // grid are searched -- LiDAR frame p50 1.71 -> 1.64 ms, ICP over a 2 M-point torus 1.68 -> 1.48 ms per iteration at
+        // 16 instead of 8; 64 bytes per point at most.)
+        const double dense_factor = ctx->knobs.dense_factor;
         // Key + sort; in automatic mode, shrink the cells while a random point shares its cell with
         // far more points than intended (surfaces and clusters fill few cells of the box densely).
         // Where smaller cells separate nothing -- as many occupied cells as before: the crowd in a cell is copies
@@ -981,7 +983,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
                 else
                     hipLaunchKernelGGL(k_cell_keys32<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st,
                                        (const double *)xyz_dev, n, g->gp, keys.as<uint32_t>(), vals.as<uint32_t>(), 0);
-                // per-cell counts (the offset table before its scan) while the table stays within 8 n + 4096
+                // per-cell counts (the offset table before its scan) while the table stays within 16 n + 4096
                 // cells; emptier grids keep the sorted keys instead and are searched
                 dense = (double)g->ncell <= dense_factor * (double)n + 4096.0;
                 // (small clouds only: their sorts are launch-bound; 66 M points on a first edge of 270 points per cell took
