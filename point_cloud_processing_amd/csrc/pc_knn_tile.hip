@@ -816,6 +816,17 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
                     if (more) lv[nlv++] = more;
                 }
             }
+            // (external queries are sorted into the next level's cells before they can be listed: not before a count has
+            // shown that the ladder goes on -- an ICP iteration whose queries are all answered at the finest level binned
+            // them a second time for nothing, a sixth of the iteration)
+            if (qrec0 && !counted && i + 1 < nlv) {
+                PC_TRY(pc_compact_flags(ctx, qflag, (int64_t)npt, nullptr, &open, st));
+                counted = true;
+                if (open < std::max<int64_t>(2048, A.nq / 200)) {
+                    open_prev = open;
+                    break;
+                }
+            }
             if (batch_passes && ks <= batch_max_ks && i + 1 < nlv) {
                 const pc_grid *nl = lv[i + 1];
                 if (qrec0) {
