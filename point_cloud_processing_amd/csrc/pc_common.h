@@ -205,6 +205,7 @@ struct pc_grid {
     mutable pc_grid *finer = nullptr;
     mutable bool finer_tried = false;  // a finer grid was asked for and cannot exist (cell-key range)
     int level = 0;        // 0: finest
+    int k_hint = 0;       // the neighbour count the index was built for (levels made from another level: that level's)
     // records of one cell are ordered low x-half first (x offset inside the cell < half an edge), then by
     // original index: the tile kernel of evenly filled fp32 grids walks 2.5 cells per row instead of 3
     bool halves = false;

@@ -797,6 +797,7 @@ static int grid_build_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t 
     g->n = n;
     g->dtype = dtype;
     if (parent) g->index_space = parent->index_space;
+    g->k_hint = parent ? parent->k_hint : k_hint;
     double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     int rc = PC_OK;
     if (parent) {

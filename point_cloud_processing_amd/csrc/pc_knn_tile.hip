@@ -134,9 +134,14 @@ int build_tile_list_dense(pc_ctx *ctx, const pc_grid *g, hipStream_t st) {
 }
 
 // candidates an uneven level's tile stages (tuning knob: PC_AMD_UNEVEN_CAP)
-int uneven_cap(const pc_ctx *ctx) {
+// (An index built for few neighbours has small cells and its blocks hold a few hundred points: the smaller block lets
+// more workgroups share a CU's LDS -- 2 M points, build hint k: sphere k = 1 / 4 / 8 1.50 / 1.35 / 1.41 -> 1.10 / 1.04 /
+// 1.16 ms, torus 1.48 / 1.16 / 1.13 -> 1.17 / 0.97 / 0.97 ms, ICP iteration over the torus 1.32 -> 1.11 ms; planes
+// and clusters 0 to 8 % faster.  From k = 16 on the full block stays: 768 lost 40 % on 4 M voxels of planes + clutter.)
+int uneven_cap(const pc_ctx *ctx, const pc_grid *g) {
     if (const int e = ctx->knobs.uneven_cap) return std::min(CAND_CAP_MAX, std::max(256, e / 64 * 64));
-    return UNEVEN_CAP;
+    const int k = g ? g->k_hint : 0;
+    return k >= 1 && k <= 2 ? 384 : (k >= 1 && k <= 8 ? 512 : UNEVEN_CAP);
 }
 
 // flags[i] = listed tile i holds at least `thresh` points; *points += the points of those tiles
@@ -329,7 +334,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
         int base = g->level > 0 ? 1 : 2;
         if (const int e = g->level > 0 ? ctx->knobs.uneven_tile1 : ctx->knobs.uneven_tile0) base = std::max(1, e);
         for (int a = 0; a < 3; a++) best[a] = std::min(std::min(base, a == 0 ? MAX_NX - 2 : 6), std::max(1, (int)g->gp.dim[a]));
-        expect = uneven_cap(ctx);
+        expect = uneven_cap(ctx, g);
         waves = 1;  // (passes over few tiles take two: uneven_waves below)
     }
     int cap = ((int)expect + 63) / 64 * 64;
@@ -878,7 +883,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             A.gp = fine->gp;
             A.rec = fine->rec;
             A.ci = fine->index();
-            A.cand_cap = uneven_cap(ctx);
+            A.cand_cap = uneven_cap(ctx, g);
             A.qflag_in = qflag;
             A.qflag_out = qflag;
             A.flag_max = 255;
