@@ -98,8 +98,9 @@ print(json.load(open(f"profiles/{R}_pmc_sq_tile_kernel.json"))["derived"])
 
 # ---- the other configurations ----------------------------------------------------------------------------
 STEP_KERNEL = {"c3": "k_voxel_reduce", "c4": "k_voxel_reduce", "c5": "k_transform", "c2": None}
-SEARCH = ("k_tile_scan", "k_batch_scan", "k_wave_query", "k_scan<", "k_collect_flagged", "k_open_flags", "k_open_range", "k_tile_full",
-          "k_tile_nonempty", "k_tile_ids", "k_key_heads", "k_take", "k_compact", "k_fill_slots")
+SEARCH = ("k_tile_scan", "k_batch_scan", "k_ring_scan", "k_wave_query", "k_scan<", "k_collect_flagged", "k_open_flags", "k_open_range",
+          "k_tile_full", "k_tile_postpone", "k_flag_hist", "k_tile_nonempty", "k_tile_ids", "k_key_heads", "k_take", "k_compact",
+          "k_fill_slots")
 BINNING = ("k_cell_keys32<", "k_radix", "k_scan_", "k_gather_records")
 for c in ("c2", "c3", "c4", "c5"):
     if not os.path.exists(f"{P}/bench_{c}.json"):
