@@ -30,6 +30,7 @@ struct PcKnobs {
     int tile_waves = 0;            // PC_AMD_TILE_WAVES (0: default)
     int tile[3] = {0, 0, 0};       // PC_AMD_TILE "tx,ty,tz" (0: automatic)
     int uneven_tile0 = 0, uneven_tile1 = 0;  // PC_AMD_UNEVEN_TILE0 / _TILE1 (0: default)
+    int thin_tile = 0;             // PC_AMD_THIN_TILE: tile edge (cells) of a coarser level that answers millions of queries (0: default)
     int uneven_waves = 0;          // PC_AMD_UNEVEN_WAVES (0: default)
     bool exact_scan_only = false;  // PC_AMD_EXACT_SCAN_ONLY: one-query-per-lane fp64 scan only (A/B switch)
     bool no_batch = false;         // PC_AMD_NO_BATCH

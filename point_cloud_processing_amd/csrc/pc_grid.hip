@@ -98,6 +98,7 @@ PcKnobs pc_read_knobs() {
         k.no_finer = on("PC_AMD_NO_FINER");
         k.no_bucket_build = on("PC_AMD_NO_BUCKET_BUILD");
         k.no_ring = on("PC_AMD_NO_RING");
+        k.thin_tile = (int)num("PC_AMD_THIN_TILE", 0);
         k.no_probe = on("PC_AMD_NO_PROBE");
         if (const char *e = getenv("PC_AMD_DENSE_FACTOR")) k.dense_factor = atof(e);
         k.no_postpone = on("PC_AMD_NO_POSTPONE");

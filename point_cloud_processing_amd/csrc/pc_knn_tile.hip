@@ -360,7 +360,8 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
             ctx->release(g->tile_list);
             g->tile_list = nullptr;
             g->tile_count = 0;
-            for (int a = 0; a < 3; a++) g->tile[a] = std::min(2, std::max(1, (int)g->gp.dim[a]));
+            // (3x3x3 since over-full tiles split twice, down to single cells: the same cloud's level 2, 48 -> 35 ms)
+            for (int a = 0; a < 3; a++) g->tile[a] = std::min(ctx->knobs.thin_tile > 0 ? ctx->knobs.thin_tile : 3, std::max(1, (int)g->gp.dim[a]));
             g->tile_cap = CAND_CAP_MAX;
             grow = 2;  // (one more turn of the loop to list the tiles, then done)
             continue;

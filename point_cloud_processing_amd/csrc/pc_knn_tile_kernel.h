@@ -904,27 +904,41 @@ void k_tile_scan(ScanArgs A) {
         tile_body<REC, KS, MODE, false>(A, smem, c0, ext, false);
         return;
     }
-    // The whole tile first; if its block is too full for LDS, its (up to) eight half-size parts
-    // one after the other: big tiles fill the waves where the cloud is thin without giving up
-    // the dense parts.
-    const int half[3] = {(ext[0] + 1) / 2, (ext[1] + 1) / 2, (ext[2] + 1) / 2};
-    int nsub = 0;
-    for (int sub = -1; sub < nsub; sub++) {
-        int sc0[3], sext[3];
+    // The whole tile first; if its block is too full for LDS, its (up to) eight half-size parts one after the other, and
+    // a part that is too full still, its own eight parts: big tiles fill the waves where the cloud is thin without
+    // giving up the dense parts (a tile of 3x3x3 cells comes down to single cells next to a wall).  One call site of
+    // the tile's body: s1 / s2 name the part (of the tile) and the part of the part being worked on, -1: the whole.
+    int s1 = -1, s2 = -1;
+    for (;;) {
+        int bc0[3] = {c0[0], c0[1], c0[2]}, bext[3] = {ext[0], ext[1], ext[2]};
         bool empty = false;
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const int hi_part = sub < 0 ? 0 : (sub >> a) & 1;
-            sc0[a] = c0[a] + hi_part * half[a];
-            sext[a] = sub < 0 ? ext[a] : (hi_part ? ext[a] - half[a] : half[a]);
-            empty |= sext[a] <= 0 || sc0[a] >= A.gp.dim[a];
+        for (int lvl = 0; lvl < 2; lvl++) {
+            const int sub = lvl == 0 ? s1 : s2;
+            if (sub < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const int half = (bext[a] + 1) / 2, hi_part = (sub >> a) & 1;
+                bc0[a] += hi_part * half;
+                bext[a] = hi_part ? bext[a] - half : half;
+                empty |= bext[a] <= 0 || bc0[a] >= A.gp.dim[a];
+            }
         }
-        if (empty) continue;
-        const int again = tile_body<REC, KS, MODE, true>(A, smem, sc0, sext, sub < 0);
-        if (sub < 0) {
+        int again = 0;
+        if (!empty) again = tile_body<REC, KS, MODE, true>(A, smem, bc0, bext, s2 < 0);
+        if (s1 < 0) {
             if (!again) break;
-            nsub = 8;
+            s1 = 0;
+        } else if (s2 < 0) {
+            if (again)
+                s2 = 0;
+            else
+                s1++;
+        } else if (++s2 == 8) {
+            s2 = -1;
+            s1++;
         }
+        if (s1 == 8) break;
     }
 }
 
