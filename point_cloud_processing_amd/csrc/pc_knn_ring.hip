@@ -26,7 +26,8 @@ constexpr int PARK_SLOTS = 16;  // parked (key, position) pairs per lane between
 constexpr int AHEAD = 8;        // candidate records in flight per lane
 constexpr int ROWS_AHEAD = 4;   // row look-ups in flight per lane
 constexpr int LOOSE_ROWS = 4;   // ... while no bound cuts anything
-constexpr int RING_MAX = 4;     // widest ring of cells a pass walks (81 rows)
+constexpr int RING_MAX = 6;     // widest ring of cells a lane walks (169 rows) when it comes with a bound
+constexpr int RING_FREE = 4;    // ... and when it has to find its bound on the way (its first rows are walked over this many cells either side)
 
 template <typename REC, int KS, int MODE>
 __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_ring_scan(ScanArgs A, const int32_t *__restrict__ list, uint32_t count,
@@ -70,6 +71,10 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
     };
     double ub = active ? (double)A.qub_arr[qid] : 0.0;  // upper bound of the k-th squared distance, or +inf
     const double ub_in = ub;
+    // (A lane without a bound walks its first rows uncut, RING_FREE cells either side: its ball must fit that.  66 M voxels:
+    // 6 cells for every lane took the pass from 25 to 30 ms; a slab of an eighth of them, whose list pass hands over
+    // 0.46 M queries with bounds that need five cells, from 0.24 M to all of them answered here.)
+    const int reach = ub < INFINITY ? RING_MAX : RING_FREE;
     bool live = active;  // still walking
     bool done = false;   // every point within `ub` was looked at
     // the list: (key + KEY_BIAS, sorted position) as the two halves of a positive, normal fp64 number, whose order is
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
                 if (shell - 1 >= 1 && ub < INFINITY && ring_for(ub) <= shell - 1) {
                     done = true;
                     live = false;
-                } else if (shell > RING_MAX) {
+                } else if (shell > reach) {
                     live = false;
                 }
             }
@@ -169,11 +174,11 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
                     span[w] = 0;
                 }
                 const bool bounded = ub < INFINITY;
-                const bool tight = bounded && ring_for(ub) <= RING_MAX;
+                const bool tight = bounded && ring_for(ub) <= reach;
                 // What is cut away is decided in fp32, in cells, on the generous side: the squared radius a ten-thousandth
                 // wider, the chord a thousandth of a cell longer (the coordinates inside the ring are small numbers).
                 const float ubc = bounded ? (float)(ub * gp.s * gp.s) * 1.0001f + 1e-4f : 0.f;
-                const int xlo = max(c[0] - RING_MAX, 0), xhi = min(c[0] + RING_MAX, gp.dim[0] - 1);
+                const int xlo = max(c[0] - reach, 0), xhi = min(c[0] + reach, gp.dim[0] - 1);
                 while (idx < nrows) {
                     if (got >= (tight ? ROWS_AHEAD : LOOSE_ROWS)) break;
                     int dy = 0, dz = 0;

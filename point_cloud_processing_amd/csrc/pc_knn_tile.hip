@@ -391,7 +391,7 @@ int choose_tile(pc_ctx *ctx, const pc_grid *g, hipStream_t st, int64_t listed = 
 // clutter: 304 -> 326 ms).  Four waves measured slower everywhere.
 int uneven_waves(const pc_ctx *ctx, int64_t tiles) {
     if (const int e = ctx->knobs.uneven_waves) return std::min(MAX_TILE_WAVES, std::max(1, e));
-    return tiles < 32768 ? 2 : 1;
+    return tiles < 8192 ? 2 : 1;
 }
 
 // After the multi-level passes: the points still flagged, as (sorted position at level 0, bound).
