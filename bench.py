@@ -428,21 +428,22 @@ def bench_c4(h):
         return v
 
     def step():
+        if h.world > 1 or args.slabs:
+            # every rank voxelises its own z layers of voxels (+ halo layers) of the raw cloud, indexes and searches
+            # those; the ranks exchange voxel counts, the number of answers no slab vouches for (any: every rank takes
+            # the replicated voxel pass and index instead) and what the filter exchanges
+            sh, kept, stats, mm = t("voxel_layers_slab_index_search_filter_ms", lambda: PD.run(PD.voxel_pipeline_steps_slab(
+                eng, xyz, 0.05, K, 2.0, {"xyz": xyz}, h.rank, h.world, want_normals=False, d2_dtype=torch.float32)))
+            parts["slabbed"] = "sub_n" in sh
+            if parts["slabbed"]:
+                parts["sub_n"] = sh["sub_n"]
+            return mm, len(kept), sh
         m = C.c_int64(0)
         t("voxel_ms", lambda: eng._check(lib.pc_voxel_downsample(ctx, _ptr(xyz), _lib.PC_F32, None, None, n, 0.05, _ptr(out),
                                                                   None, None, None, None, C.byref(m), eng.stream()), "voxel"))
         mm = m.value
         cent = out[:mm]
         cache = {"xyz": cent}
-        if h.world > 1 or args.slabs:
-            # every rank indexes and searches only its own z interval of the voxel cloud (+ halo); one all-reduce puts
-            # the mean distances together; falls back to the replicated index where the slabs cannot vouch for an answer
-            sh, kept, stats = t("slab_index_search_filter_ms", lambda: PD.run(PD.pipeline_steps_slab(
-                eng, cent, K, 2.0, cache, h.rank, h.world, want_normals=False, d2_dtype=torch.float32)))
-            parts["slabbed"] = "sub_n" in sh
-            if parts["slabbed"]:
-                parts["sub_n"] = sh["sub_n"]
-            return mm, len(kept), sh
         b, e = PD.shard_positions(mm, h.rank, h.world)
         t("index_build_ms", lambda: eng.grid(cent, cache, K))
         sh = t("search_ms", lambda: eng.shard_search(cent, cache, K, -1.0, b, e, want_rows=True, want_avg=True,
@@ -462,13 +463,13 @@ def bench_c4(h):
         tot.append(time.perf_counter() - t0)
     dt = min(tot)
     alg_knn = knn_algorithmic_bytes(len(sh["owned"]), mm, K, per_query_extra=8)
-    search_ms = parts.get("search_ms", parts.get("slab_index_search_filter_ms"))
+    search_ms = parts.get("search_ms", parts.get("voxel_layers_slab_index_search_filter_ms"))
     r = base_result(h, "points/sec (100M-pt scan: voxel 0.05 m + kNN k=32 + statistical filter)", n / dt, "points/s", dt * 1e3,
                     f"configs[3]: {n} points, 70 % on random planar patches + 30 % uniform clutter, extent 200 m (seeds 5..); "
                     f"voxel_down_sample(0.05) -> {mm} voxels (fp64 centroids) -> index -> kNN(32) rows + mean distances of the "
                     f"rank's slice -> statistical filter (std 2.0), kept {nk}",
                     {"points": n, "voxels": mm, "k": K,
-                     "parallelism": (f"z-slab x{h.world}: replicated voxel pass, per-rank slab index" if parts.get("slabbed") else
+                     "parallelism": (f"z-slab x{h.world}: per-rank voxel layers and slab index" if parts.get("slabbed") else
                                      f"query-shard x{h.world}, replicated voxel pass and index")})
     r["steps"], r["warmup"] = reps, 1
     r["step_parts_ms"] = parts
@@ -478,7 +479,7 @@ def bench_c4(h):
                      "traffic_source": "not collected", "algorithmic_bytes_per_launch": alg_knn,
                      "kernel_ms": search_ms}
     if "search_ms" not in parts:
-        r["roofline"]["kernel"] += " -- timed with the slab's subset, index and filter around it (slab path)"
+        r["roofline"]["kernel"] += " -- timed with the slab's voxel layers, index and filter around it (slab path)"
     elif n == 100_000_000 and h.world == 1:
         tr, src, _ = config_traffic("c4")
         r["roofline"]["traffic"], r["roofline"]["traffic_source"] = tr, src

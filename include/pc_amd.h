@@ -88,6 +88,17 @@ int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const doubl
                         const double *colors_dev, int64_t n, double voxel_size, double *out_xyz_dev,
                         double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
                         int32_t *out_ijk_dev, int64_t *out_m, void *stream);
+/* No reference counterpart (the reference has no distribution): the voxels of the layers layer_lo <= iz < layer_hi of
+ * the voxel grid that pc_voxel_downsample lays over a cloud whose bounding box is box_min / box_max -- the box of the
+ * WHOLE cloud, of which xyz_dev may hold all points or any part that contains the layers' points.  Same voxel
+ * indices, centroids and order as the corresponding run of pc_voxel_downsample's output; only the points inside the
+ * layers are sorted.  A rank of a multi-GPU job voxelises its own z interval (+ halo layers) with it: the voxel
+ * order is (iz, iy, ix), so a rank's voxels are one contiguous run of the whole cloud's. */
+int pc_voxel_downsample_layers(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
+                               const double *colors_dev, int64_t n, double voxel_size, const double box_min[3],
+                               const double box_max[3], int64_t layer_lo, int64_t layer_hi, double *out_xyz_dev,
+                               double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
+                               int32_t *out_ijk_dev, int64_t *out_m, void *stream);
 /* Voxel index triple of every input point (n x 3 int32) and the voxel grid dimensions. */
 int pc_voxel_assign(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double voxel_size,
                     int32_t *out_ijk_dev, int32_t out_dims[3], void *stream);

@@ -82,6 +82,16 @@ class OracleEngine:
     def voxel_downsample(self, pts, nrm, col, vs, cache):
         return O.voxel_downsample(pts, vs, nrm, col)
 
+    def voxel_layers(self, pts, cache, vs, box_min, box_max, layer_lo, layer_hi):
+        # (the whole cloud is voxelised and the layers picked: box_min / box_max are the whole cloud's box by contract)
+        p, _, _, _, ijk = O.voxel_downsample(pts, vs, with_info=True)
+        keep = (ijk[:, 2] >= layer_lo) & (ijk[:, 2] < layer_hi)
+        return np.ascontiguousarray(p[keep]), np.ascontiguousarray(ijk[keep, 2])
+
+    @staticmethod
+    def concat_rows(parts):
+        return np.concatenate(list(parts), axis=0)
+
     def normals(self, pts, k, radius, prior, cache):
         return O.normals(pts, k, radius, prior)
 
@@ -128,7 +138,8 @@ class OracleEngine:
             out[a] = np.bincount(b, minlength=nbins)
         return out
 
-    def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False, avg_full=None):
+    def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False, avg_full=None,
+                    open_faces=None):
         pts = np.asarray(pts, dtype=np.float64)
         z = pts[:, 2]
         lo, hi = own_lo - halo, own_hi + halo
@@ -141,6 +152,9 @@ class OracleEngine:
                "d2": d2, "cnt": cnt, "sub_n": len(gidx), "n_own": len(own)}
         open_lo = lo if lo > z.min() else -np.inf
         open_hi = hi if hi <= z.max() else np.inf
+        if open_faces is not None:
+            open_lo = lo if open_faces[0] else -np.inf
+            open_hi = hi if open_faces[1] else np.inf
         margin = np.minimum(q[:, 2] - open_lo, open_hi - q[:, 2])
         lim = np.where(np.isfinite(margin), margin * margin * (1.0 - 1e-9), np.inf)
         full = cnt >= k

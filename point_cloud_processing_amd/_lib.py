@@ -32,6 +32,7 @@ SYMBOLS = [
     ("pc_center", _i32, [_vp, _vp, _i32, _i64, _pd, _vp]),
     ("pc_affine", _i32, [_vp, _vp, _i64, _pd, _i32, _dbl, _pd, _vp]),
     ("pc_voxel_downsample", _i32, [_vp, _vp, _i32, _vp, _vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
+    ("pc_voxel_downsample_layers", _i32, [_vp, _vp, _i32, _vp, _vp, _i64, _dbl, _pd, _pd, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
     ("pc_voxel_assign", _i32, [_vp, _vp, _i32, _i64, _dbl, _vp, _pi32, _vp]),
     ("pc_grid_build", _i32, [_vp, _vp, _i32, _i64, _dbl, _i32, C.POINTER(_vp), _vp]),
     ("pc_grid_destroy", None, [_vp, _vp]),

@@ -314,6 +314,30 @@ __global__ __launch_bounds__(256) void k_cell_keys(const T *__restrict__ xyz, in
     }
 }
 
+// flags[i] = 1 where point i lies in a voxel layer iz with lo <= iz < hi (the voxel index expression of k_cell_keys)
+template <typename T>
+__global__ __launch_bounds__(256) void k_layer_flags(const T *__restrict__ xyz, int64_t n, GridParams gp, int64_t lo, int64_t hi,
+                                                      uint8_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t iz = (int64_t)floor(((double)xyz[3 * i + 2] - gp.o[2]) / gp.s);
+    flags[i] = iz >= lo && iz < hi ? 1 : 0;
+}
+
+// voxel keys of the selected points only: keys[j] of point sel[j], vals[j] = sel[j]
+template <typename T>
+__global__ __launch_bounds__(256) void k_cell_keys_of(const T *__restrict__ xyz, const int32_t *__restrict__ sel, int64_t m,
+                                                       GridParams gp, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t i = sel[j];
+    uint64_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) c[a] = (uint64_t)(int32_t)floor(((double)xyz[3 * i + a] - gp.o[a]) / gp.s);
+    keys[j] = (c[2] * (uint64_t)gp.dim[1] + c[1]) * (uint64_t)gp.dim[0] + c[0];
+    vals[j] = (uint32_t)i;
+}
+
 // kNN grid keys as u32 (the dense table has fewer than 2^32 cells)
 // (halfbit: one more key bit below the cell, set for points in the upper x-half of their cell -- the
 // expression x_half_of() in pc_common.h, which the tile kernel repeats)
@@ -731,33 +755,59 @@ int pc_voxel_assign(pc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, doub
     return PC_OK;
 }
 
-int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
-                        const double *colors_dev, int64_t n, double voxel_size, double *out_xyz_dev,
-                        double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
-                        int32_t *out_ijk_dev, int64_t *out_m, void *stream) {
-    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
-    if (!ctx || !out_m || n < 0 || n >= INT32_MAX || (n > 0 && (!xyz_dev || !out_xyz_dev)) ||
-        (dtype != PC_F32 && dtype != PC_F64))
-        return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_downsample");
+static int voxel_downsample_impl(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
+                                 const double *colors_dev, int64_t n, double voxel_size, const double *box_min,
+                                 const double *box_max, int64_t layer_lo, int64_t layer_hi, double *out_xyz_dev,
+                                 double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
+                                 int32_t *out_ijk_dev, int64_t *out_m, void *stream) {
     if (!(voxel_size > 0.0)) return pc_fail(ctx, PC_BAD_ARG, "voxel_size <= 0.");
     PC_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     *out_m = 0;
     if (n == 0) return PC_OK;
     double mn[3], mx[3];
-    PC_TRY(bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st));
+    if (box_min && box_max) {
+        for (int a = 0; a < 3; a++) {
+            mn[a] = box_min[a];
+            mx[a] = box_max[a];
+        }
+    } else {
+        PC_TRY(bbox_impl(ctx, xyz_dev, dtype, n, mn, mx, st));
+    }
     for (int a = 0; a < 3; a++)
-        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
+        if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]) || mx[a] < mn[a])
             return pc_fail(ctx, PC_BAD_ARG, "non-finite coordinates: the cloud has no finite bounding box");
     GridParams gp{};
     PC_TRY(voxel_params(ctx, mn, mx, voxel_size, &gp));
 
-    Scratch keys(ctx, sizeof(uint64_t) * (size_t)n), keys2(ctx, sizeof(uint64_t) * (size_t)n);
-    Scratch vals(ctx, sizeof(uint32_t) * (size_t)n), vals2(ctx, sizeof(uint32_t) * (size_t)n);
-    Scratch flags(ctx, (size_t)n), heads(ctx, sizeof(int32_t) * (size_t)n);
+    // a range of voxel layers: only the points inside it are keyed and sorted
+    const bool ranged = box_min && box_max;
+    int64_t m_in = n;
+    Scratch sel(ctx, ranged ? sizeof(int32_t) * (size_t)n : 0);
+    if (ranged) {
+        Scratch lf(ctx, (size_t)n);
+        if (!sel.ok() || !lf.ok()) return pc_fail(ctx, PC_NOMEM, "voxel scratch");
+        if (dtype == PC_F32)
+            hipLaunchKernelGGL(k_layer_flags<float>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const float *)xyz_dev, n, gp,
+                               layer_lo, layer_hi, lf.as<uint8_t>());
+        else
+            hipLaunchKernelGGL(k_layer_flags<double>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const double *)xyz_dev, n, gp,
+                               layer_lo, layer_hi, lf.as<uint8_t>());
+        PC_TRY(pc_compact_flags(ctx, lf.as<uint8_t>(), n, sel.as<int32_t>(), &m_in, st));  // (synchronises: lf goes back)
+        if (m_in == 0) return PC_OK;
+    }
+    Scratch keys(ctx, sizeof(uint64_t) * (size_t)m_in), keys2(ctx, sizeof(uint64_t) * (size_t)m_in);
+    Scratch vals(ctx, sizeof(uint32_t) * (size_t)m_in), vals2(ctx, sizeof(uint32_t) * (size_t)m_in);
+    Scratch flags(ctx, (size_t)m_in), heads(ctx, sizeof(int32_t) * (size_t)m_in);
     if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok() || !flags.ok() || !heads.ok())
         return pc_fail(ctx, PC_NOMEM, "voxel scratch");
-    if (dtype == PC_F32)
+    if (ranged && dtype == PC_F32)
+        hipLaunchKernelGGL(k_cell_keys_of<float>, dim3(blocks_for(m_in, 256)), dim3(256), 0, st, (const float *)xyz_dev,
+                           sel.as<int32_t>(), m_in, gp, keys.as<uint64_t>(), vals.as<uint32_t>());
+    else if (ranged)
+        hipLaunchKernelGGL(k_cell_keys_of<double>, dim3(blocks_for(m_in, 256)), dim3(256), 0, st, (const double *)xyz_dev,
+                           sel.as<int32_t>(), m_in, gp, keys.as<uint64_t>(), vals.as<uint32_t>());
+    else if (dtype == PC_F32)
         hipLaunchKernelGGL((k_cell_keys<float, true>), dim3(blocks_for(n, 256)), dim3(256), 0, st,
                            (const float *)xyz_dev, n, gp, keys.as<uint64_t>(), vals.as<uint32_t>(), (int32_t *)nullptr);
     else
@@ -766,24 +816,50 @@ int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const doubl
     uint64_t ncell = (uint64_t)gp.dim[0] * (uint64_t)gp.dim[1] * (uint64_t)gp.dim[2];
     bool in_tmp = false;
     PC_TRY(pc_radix_sort_pairs(ctx, keys.as<uint64_t>(), vals.as<uint32_t>(), keys2.as<uint64_t>(),
-                               vals2.as<uint32_t>(), n, bits_for(ncell - 1), st, &in_tmp));
+                               vals2.as<uint32_t>(), m_in, bits_for(ncell - 1), st, &in_tmp));
     const uint64_t *sk = in_tmp ? keys2.as<uint64_t>() : keys.as<uint64_t>();
     const uint32_t *sv = in_tmp ? vals2.as<uint32_t>() : vals.as<uint32_t>();
-    hipLaunchKernelGGL(k_segment_heads, dim3(blocks_for(n, 256)), dim3(256), 0, st, sk, n, flags.as<uint8_t>());
+    hipLaunchKernelGGL(k_segment_heads, dim3(blocks_for(m_in, 256)), dim3(256), 0, st, sk, m_in, flags.as<uint8_t>());
     int64_t m = 0;
-    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), n, heads.as<int32_t>(), &m, st));
+    PC_TRY(pc_compact_flags(ctx, flags.as<uint8_t>(), m_in, heads.as<int32_t>(), &m, st));
     if (dtype == PC_F32)
         hipLaunchKernelGGL(k_voxel_reduce<float>, dim3(blocks_for(m, 256)), dim3(256), 0, st, (const float *)xyz_dev,
-                           normals_dev, colors_dev, sk, sv, heads.as<int32_t>(), m, n, gp, out_xyz_dev,
+                           normals_dev, colors_dev, sk, sv, heads.as<int32_t>(), m, m_in, gp, out_xyz_dev,
                            out_normals_dev, out_colors_dev, out_count_dev, out_ijk_dev);
     else
         hipLaunchKernelGGL(k_voxel_reduce<double>, dim3(blocks_for(m, 256)), dim3(256), 0, st,
-                           (const double *)xyz_dev, normals_dev, colors_dev, sk, sv, heads.as<int32_t>(), m, n, gp,
+                           (const double *)xyz_dev, normals_dev, colors_dev, sk, sv, heads.as<int32_t>(), m, m_in, gp,
                            out_xyz_dev, out_normals_dev, out_colors_dev, out_count_dev, out_ijk_dev);
     PC_HIP(hipGetLastError());
     PC_HIP(hipStreamSynchronize(st));  // scratch is released on return
     *out_m = m;
     return PC_OK;
+}
+
+int pc_voxel_downsample(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
+                        const double *colors_dev, int64_t n, double voxel_size, double *out_xyz_dev,
+                        double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
+                        int32_t *out_ijk_dev, int64_t *out_m, void *stream) {
+    PcLock lock(ctx, stream);  // calls on one context take turns (its block pool and read-back buffer are shared)
+    if (!ctx || !out_m || n < 0 || n >= INT32_MAX || (n > 0 && (!xyz_dev || !out_xyz_dev)) ||
+        (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_downsample");
+    return voxel_downsample_impl(ctx, xyz_dev, dtype, normals_dev, colors_dev, n, voxel_size, nullptr, nullptr, 0, 0,
+                                 out_xyz_dev, out_normals_dev, out_colors_dev, out_count_dev, out_ijk_dev, out_m, stream);
+}
+
+int pc_voxel_downsample_layers(pc_ctx *ctx, const void *xyz_dev, int dtype, const double *normals_dev,
+                               const double *colors_dev, int64_t n, double voxel_size, const double box_min[3],
+                               const double box_max[3], int64_t layer_lo, int64_t layer_hi, double *out_xyz_dev,
+                               double *out_normals_dev, double *out_colors_dev, int32_t *out_count_dev,
+                               int32_t *out_ijk_dev, int64_t *out_m, void *stream) {
+    PcLock lock(ctx, stream);
+    if (!ctx || !out_m || !box_min || !box_max || n < 0 || n >= INT32_MAX || (n > 0 && (!xyz_dev || !out_xyz_dev)) ||
+        (dtype != PC_F32 && dtype != PC_F64))
+        return pc_fail(ctx, PC_BAD_ARG, "pc_voxel_downsample_layers");
+    return voxel_downsample_impl(ctx, xyz_dev, dtype, normals_dev, colors_dev, n, voxel_size, box_min, box_max, layer_lo,
+                                 layer_hi, out_xyz_dev, out_normals_dev, out_colors_dev, out_count_dev, out_ijk_dev, out_m,
+                                 stream);
 }
 
 // The index of a cloud given as an array (parent == NULL), or of the cloud another level of the same index

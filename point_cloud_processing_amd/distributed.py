@@ -52,11 +52,19 @@ def run(gen, group=None):
     """Drive one rank's generator: every yielded array is summed over the ranks of ``group``, in place
     (a process without a process group is a world of one: nothing to add)."""
     alone = not (dist.is_available() and dist.is_initialized())
+    # (gloo with device tensors -- rehearsals of several ranks on one GPU -- stages through the host on streams of its
+    # own: the device is brought to rest around every exchange; seen to hang otherwise on the second job of a process)
+    fence = not alone and dist.get_backend(group) == "gloo"
     try:
         x = next(gen)
         while True:
             if not alone:
-                dist.all_reduce(_as_tensor(x), op=dist.ReduceOp.SUM, group=group)
+                t = _as_tensor(x)
+                if fence and t.is_cuda:
+                    torch.cuda.synchronize(t.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                if fence and t.is_cuda:
+                    torch.cuda.synchronize(t.device)
             x = gen.send(x)
     except StopIteration as stop:
         return stop.value
@@ -177,19 +185,24 @@ def slab_cuts(engine, pts, cache: dict, k: int, world: int):
         b = int(np.searchsorted(cum, (r * n) // world))  # first bin whose running count reaches the rank's share
         cuts.append(float(mn[2] + (b + 1) * width[2]))
     cuts.append(np.inf)
-    # the box of the cloud's bulk (all but half a per cent of the points at either end of every axis): a few stray
-    # points far out would otherwise inflate the volume, and with it the halo, until no slab is worth making
-    bulk = np.empty(3)
-    for a in range(3):
-        c = np.cumsum(hist[a])
-        b0, b1 = int(np.searchsorted(c, n // 200)), int(np.searchsorted(c, n - n // 200))
-        bulk[a] = (b1 - b0 + 1) * width[a]
-    floor_ext = np.maximum(bulk, 1e-3 * bulk.max())
-    halo = SLAB_HALO * float((k * np.prod(floor_ext) / n) ** (1.0 / 3.0))
+    halo = _bulk_halo(hist, width, n, n, k)
     inner = np.diff(np.array([mn[2]] + cuts[1:-1] + [mx[2]]))
     if not (np.diff(cuts[1:-1]) > 0).all() or inner.min() < 2.0 * halo:
         return None
     return cuts, halo
+
+
+def _bulk_halo(hist, width, n_hist: int, n_points: int, k: int) -> float:
+    """The halo of a slab: ``SLAB_HALO`` times the neighbour distance of ``n_points`` points spread evenly over the box
+    of the cloud's bulk -- all but half a per cent of the ``n_hist`` histogrammed points at either end of every axis: a
+    few stray points far out would otherwise inflate the volume, and with it the halo, until no slab is worth making."""
+    bulk = np.empty(3)
+    for a in range(3):
+        c = np.cumsum(hist[a])
+        b0, b1 = int(np.searchsorted(c, n_hist // 200)), int(np.searchsorted(c, n_hist - n_hist // 200))
+        bulk[a] = (b1 - b0 + 1) * width[a]
+    floor_ext = np.maximum(bulk, 1e-3 * bulk.max())
+    return SLAB_HALO * float((k * np.prod(floor_ext) / max(n_points, 1)) ** (1.0 / 3.0))
 
 
 SLAB_REPEAT_MAX = 1 << 16  # answers repeated across the ranks at most; beyond, the job goes to the replicated index
@@ -256,6 +269,82 @@ def pipeline_steps_slab(engine, pts, k: int, std_ratio: float, cache: dict, rank
         yield from _repeat_unvouched(engine, pts, cache, k, sh, None, rank, world, total, want_normals)
     kept, stats = yield from _filter_core(engine, sh, n, std_ratio)
     return sh, kept, stats
+
+
+def voxel_layer_cuts(engine, raw, cache: dict, voxel: float, world: int):
+    """Voxel layers along z per rank: ``(box_min, box_max, origin_z, cuts, hist, width)`` with rank r owning the layers
+    ``cuts[r] <= iz < cuts[r + 1]`` of the voxel grid ``voxel_down_sample`` lays over the cloud, cut so that the ranks hold
+    about n / world raw points each.  ``None`` where the cloud has too few layers for that."""
+    n = len(raw)
+    mn, mx = engine.bbox(raw, cache)
+    mn, mx = np.asarray(mn, dtype=np.float64), np.asarray(mx, dtype=np.float64)
+    oz = mn[2] - 0.5 * voxel                       # (the voxel grid's origin: min bound minus half a voxel)
+    nlayers = int(np.floor((mx[2] - oz) / voxel)) + 1
+    if world <= 1:
+        return mn, mx, oz, [0, nlayers], None, None
+    if n < 2 * world or nlayers < 4 * world:
+        return None
+    hist = np.asarray(engine.axes_histogram(raw, cache, mn, mx, SLAB_BINS), dtype=np.int64)
+    cum = np.cumsum(hist[2])
+    width = (mx - mn) / SLAB_BINS
+    cuts = [0]
+    for r in range(1, world):
+        b = int(np.searchsorted(cum, (r * n) // world))
+        cuts.append(int(round((mn[2] + (b + 1) * width[2] - oz) / voxel)))
+    cuts.append(nlayers)
+    if not (np.diff(cuts) > 0).all():
+        return None
+    return mn, mx, oz, cuts, hist, width
+
+
+def voxel_pipeline_steps_slab(engine, raw, voxel: float, k: int, std_ratio: float, cache: dict, rank: int, world: int,
+                              want_normals: bool = True, **search_kw):
+    """Voxel down-sampling + ``pipeline_steps_slab`` where no rank ever voxelises the whole cloud: every rank holds the
+    raw cloud, voxelises the z layers of voxels it owns plus a halo of layers (``pc_voxel_downsample_layers``: the
+    whole cloud's voxel grid, so a rank's voxels are one contiguous run of ``voxel_down_sample``'s output and indices
+    translate by one addition), indexes those and answers its own.  The ranks exchange their voxel counts (the
+    offsets), the number of answers their slabs cannot vouch for and what the filter exchanges.  If any answer is
+    unvouched, or the cloud has too few layers, every rank takes the replicated voxel pass and ``pipeline_steps_slab``
+    instead: exact either way.  Returns ``(rows, kept, stats, m)``: rows and kept indices in indices of the whole
+    down-sampled cloud of ``m`` voxels."""
+    def replicated():
+        vox = engine.voxel_downsample_dev(raw, None, None, voxel, cache)[0] if hasattr(engine, "voxel_downsample_dev") \
+            else engine.voxel_downsample(raw, None, None, voxel, cache)[0]
+        sh, kept, stats = yield from pipeline_steps_slab(engine, vox, k, std_ratio, {}, rank, world, want_normals, **search_kw)
+        return sh, kept, stats, len(vox)
+
+    plan = voxel_layer_cuts(engine, raw, cache, voxel, world)
+    if world <= 1 or plan is None:
+        return (yield from replicated())
+    mn, mx, oz, cuts, hist, width = plan
+    lo, hi = cuts[rank], cuts[rank + 1]
+    own, _ = engine.voxel_layers(raw, cache, voxel, mn, mx, lo, hi)
+    counts = engine.zeros((world,), "f64")
+    counts[rank] = float(len(own))
+    counts = yield counts
+    counts = np.asarray(engine.to_host(counts)).astype(np.int64)
+    m = int(counts.sum())
+    halo_layers = int(np.ceil(_bulk_halo(hist, width, len(raw), m, k) / voxel))
+    if min(np.diff(cuts)) < 2 * halo_layers or m < 2 * world:  # (every rank finds the same)
+        return (yield from replicated())
+    lower = engine.voxel_layers(raw, cache, voxel, mn, mx, lo - halo_layers, lo)[0] if rank > 0 else own[:0]
+    upper = engine.voxel_layers(raw, cache, voxel, mn, mx, hi, hi + halo_layers)[0] if rank < world - 1 else own[:0]
+    local = engine.concat_rows([lower, own, upper])
+    base = int(counts[:rank].sum()) - len(lower)  # index of local row 0 in the whole down-sampled cloud
+    own_lo = oz + lo * voxel if rank > 0 else -np.inf
+    own_hi = oz + hi * voxel if rank < world - 1 else np.inf
+    sh = engine.slab_search(local, {}, k, -1.0, own_lo, own_hi, halo_layers * voxel, want_avg=True, want_normals=want_normals,
+                            open_faces=(rank > 0, rank < world - 1), **search_kw)
+    count = engine.zeros((1,), "f64")
+    count[0] = float(sh["n_uncertain"])
+    count = yield count
+    if int(float(count[0])) > 0:
+        return (yield from replicated())
+    for key in ("owned", "idx"):
+        a = sh[key]
+        a[a >= 0] += base
+    kept, stats = yield from _filter_core(engine, sh, m, std_ratio)
+    return sh, kept, stats, m
 
 
 def knn_slab_steps(engine, pts, k: int, cache: dict, rank: int, world: int, **search_kw):

@@ -219,6 +219,26 @@ class HipEngine:
         # (own storage of m rows each: the n-row output buffers go back to the allocator)
         return (op[:m].clone(), None if on is None else on[:m].clone(), None if oc is None else oc[:m].clone())
 
+    def voxel_layers(self, pts, cache, vs, box_min, box_max, layer_lo, layer_hi):
+        """The voxels of the z layers ``layer_lo <= iz < layer_hi`` of the voxel grid over the box of the WHOLE cloud:
+        ``(centroids, iz)`` on the device, the same rows and order as that run of ``voxel_downsample``'s output."""
+        n = len(pts)
+        t = self.dev_points(pts, cache)
+        op = self.empty((max(n, 1), 3), torch.float64)
+        ijk = self.empty((max(n, 1), 3), torch.int32)
+        m = C.c_int64(0)
+        mn = (C.c_double * 3)(*[float(v) for v in box_min])
+        mx = (C.c_double * 3)(*[float(v) for v in box_max])
+        self._check(self.lib.pc_voxel_downsample_layers(self.ctx, _ptr(t), self._dt(t), None, None, n, float(vs), mn, mx,
+                                                        int(layer_lo), int(layer_hi), _ptr(op), None, None, None, _ptr(ijk),
+                                                        C.byref(m), self.stream()), "pc_voxel_downsample_layers")
+        m = m.value
+        return op[:m].clone(), ijk[:m, 2].clone()
+
+    @staticmethod
+    def concat_rows(parts):
+        return torch.cat(list(parts), dim=0)
+
     def voxel_downsample(self, pts, nrm, col, vs, cache):
         p, n, c = self.voxel_downsample_dev(pts, nrm, col, vs, cache)
         return p.cpu().numpy(), None if n is None else n.cpu().numpy(), None if c is None else c.cpu().numpy()
@@ -420,11 +440,12 @@ class HipEngine:
         return out
 
     def slab_search(self, pts, cache, k, radius, own_lo, own_hi, halo, want_avg=False, want_normals=False,
-                    d2_dtype=torch.float64, avg_full=None, stage_ms: Optional[dict] = None):
+                    d2_dtype=torch.float64, avg_full=None, stage_ms: Optional[dict] = None, open_faces=None):
         """The rank's queries (own_lo <= z < own_hi) answered from an index of the points with z in
         [own_lo - halo, own_hi + halo) only.  Rows as in ``shard_search`` (always with idx / d2 / cnt), indices
         those of the whole cloud; rows with ``owned`` < 0 belong to a neighbouring rank and are to be ignored.
-        ``n_uncertain``: own answers the slab cannot vouch for (see pc_slab_finish).  ``avg_full`` (n doubles or
+        ``n_uncertain``: own answers the slab cannot vouch for (see pc_slab_finish).  ``open_faces`` = (low, high): whether
+        the cloud goes on beyond the slab's low / high face, for callers whose ``pts`` holds only the slab itself.  ``avg_full`` (n doubles or
         more): receives the own rows' mean distances at their index in the whole cloud.  ``stage_ms``: a dict
         that receives the time of each stage (synchronises after every stage: measurements only)."""
         import time
@@ -488,6 +509,9 @@ class HipEngine:
             # faces of the subset beyond which the cloud goes on
             open_lo = float(lo) if lo > mn[2] else -np.inf
             open_hi = float(hi) if hi <= mx[2] else np.inf
+            if open_faces is not None:  # (``pts`` is only a part of the cloud: the caller knows where it goes on)
+                open_lo = float(lo) if open_faces[0] else -np.inf
+                open_hi = float(hi) if open_faces[1] else np.inf
             self._check(self.lib.pc_slab_finish(self.ctx, _ptr(t), self._dt(t), None, rows, int(k), float(radius),
                                                 _ptr(out["idx"]), _ptr(out["d2"]), self._dt(out["d2"]), _ptr(out["cnt"]),
                                                 _ptr(out["owned"]), float(own_lo), float(own_hi), open_lo, open_hi,

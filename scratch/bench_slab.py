@@ -71,7 +71,22 @@ for world in (1, 2, 4, 8):
                 stages = {a: round(b, 3) for a, b in st.items()}
             slab.append(ms); sub.append(sh["sub_n"]); unc += sh["n_uncertain"]; own += sh["n_own"]
             del sh, c
-    w = {"replicated_build_ms": build_ms, "replicated_search_ms_max": max(rep), "replicated_rank_ms": build_ms + max(rep),
+    vox_layers = []
+    if what != "headline" and world > 1:
+        vplan = PD.voxel_layer_cuts(eng, raw, {}, 0.05, world)
+        if vplan is not None:
+            mn_, mx_, oz_, vcuts, vh, vw = vplan
+            hl = int(np.ceil(PD._bulk_halo(vh, vw, raw.shape[0], n, k) / 0.05))
+            vc = {"xyz": raw}
+            for r in range(world):
+                def layers(r=r):
+                    a = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r], vcuts[r + 1])[0]
+                    b = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r] - hl, vcuts[r])[0] if r > 0 else a[:0]
+                    c = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r + 1], vcuts[r + 1] + hl)[0] if r < world - 1 else a[:0]
+                    return eng.concat_rows([b, a, c])
+                layers()
+                vox_layers.append(timed(layers)[1])
+    w = {"voxel_layers_rank_ms": vox_layers, "replicated_build_ms": build_ms, "replicated_search_ms_max": max(rep), "replicated_rank_ms": build_ms + max(rep),
          "slab_rank_ms_max": max(slab) if slab else None, "slab_rank_ms": slab, "slab_points": sub, "uncertain": unc,
          "own_total": own, "stages_of_a_middle_rank_ms": stages, "plan": None if plan is None else {"halo": plan[1]}}
     res["worlds"][world] = w
@@ -82,5 +97,8 @@ for world, w in res["worlds"].items():
     line = f"W={world}: replicated {rep:.2f} ms/rank ({(one_gpu + voxel_ms) / (rep + voxel_ms):.2f}x)"
     if w["slab_rank_ms_max"]:
         line += f"; slabs {w['slab_rank_ms_max']:.2f} ms/rank ({(one_gpu + voxel_ms) / (w['slab_rank_ms_max'] + voxel_ms):.2f}x with the voxel pass replicated)"
+        if w["voxel_layers_rank_ms"]:
+            both = max(a + b for a, b in zip(w["voxel_layers_rank_ms"], w["slab_rank_ms"]))
+            line += f"; with the voxel pass by layers {both:.2f} ms/rank ({(one_gpu + voxel_ms) / both:.2f}x)"
     print(line)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"slab_{what}.json"), "w"), indent=1)
