@@ -92,6 +92,10 @@ class OracleEngine:
     def concat_rows(parts):
         return np.concatenate(list(parts), axis=0)
 
+    @staticmethod
+    def sorted_positions(sorted_arr, values):
+        return [int(x) for x in np.searchsorted(np.asarray(sorted_arr), [int(v) for v in values])]
+
     def normals(self, pts, k, radius, prior, cache):
         return O.normals(pts, k, radius, prior)
 

@@ -318,19 +318,34 @@ def voxel_pipeline_steps_slab(engine, raw, voxel: float, k: int, std_ratio: floa
         return (yield from replicated())
     mn, mx, oz, cuts, hist, width = plan
     lo, hi = cuts[rank], cuts[rank + 1]
-    own, _ = engine.voxel_layers(raw, cache, voxel, mn, mx, lo, hi)
+    # own layers and a guessed halo in ONE pass over the raw cloud (the halo wanted follows from the number of voxels,
+    # which only the exchange of the counts tells: guessed from half as many voxels as points; layers missing after
+    # that are fetched, layers too many dropped)
+    guess = int(np.ceil(_bulk_halo(hist, width, len(raw), max(len(raw) // 2, 1), k) / voxel))
+    g_lo, g_hi = (lo - guess if rank > 0 else lo), (hi + guess if rank < world - 1 else hi)
+    local, iz = engine.voxel_layers(raw, cache, voxel, mn, mx, g_lo, g_hi)
+    at = lambda *layers: engine.sorted_positions(iz, layers)  # (iz ascends: the voxel order is (iz, iy, ix))
+    p_lo, p_hi = at(lo, hi)
+    n_own = p_hi - p_lo
     counts = engine.zeros((world,), "f64")
-    counts[rank] = float(len(own))
+    counts[rank] = float(n_own)
     counts = yield counts
     counts = np.asarray(engine.to_host(counts)).astype(np.int64)
     m = int(counts.sum())
     halo_layers = int(np.ceil(_bulk_halo(hist, width, len(raw), m, k) / voxel))
     if min(np.diff(cuts)) < 2 * halo_layers or m < 2 * world:  # (every rank finds the same)
         return (yield from replicated())
-    lower = engine.voxel_layers(raw, cache, voxel, mn, mx, lo - halo_layers, lo)[0] if rank > 0 else own[:0]
-    upper = engine.voxel_layers(raw, cache, voxel, mn, mx, hi, hi + halo_layers)[0] if rank < world - 1 else own[:0]
-    local = engine.concat_rows([lower, own, upper])
-    base = int(counts[:rank].sum()) - len(lower)  # index of local row 0 in the whole down-sampled cloud
+    w_lo, w_hi = (lo - halo_layers if rank > 0 else lo), (hi + halo_layers if rank < world - 1 else hi)
+    a, b = at(max(w_lo, g_lo), min(w_hi, g_hi))
+    parts = [local[a:b]]
+    if w_lo < g_lo:
+        parts.insert(0, engine.voxel_layers(raw, cache, voxel, mn, mx, w_lo, g_lo)[0])
+    if w_hi > g_hi:
+        parts.append(engine.voxel_layers(raw, cache, voxel, mn, mx, g_hi, w_hi)[0])
+    n_lower = len(parts[0]) if w_lo < g_lo else 0
+    n_lower += p_lo - a
+    local = engine.concat_rows(parts) if len(parts) > 1 else parts[0]
+    base = int(counts[:rank].sum()) - n_lower  # index of local row 0 in the whole down-sampled cloud
     own_lo = oz + lo * voxel if rank > 0 else -np.inf
     own_hi = oz + hi * voxel if rank < world - 1 else np.inf
     sh = engine.slab_search(local, {}, k, -1.0, own_lo, own_hi, halo_layers * voxel, want_avg=True, want_normals=want_normals,

@@ -239,6 +239,12 @@ class HipEngine:
     def concat_rows(parts):
         return torch.cat(list(parts), dim=0)
 
+    @staticmethod
+    def sorted_positions(sorted_dev: torch.Tensor, values) -> list:
+        """First position of every value in an ascending device array (only the answers visit the host)."""
+        v = torch.tensor([int(x) for x in values], dtype=sorted_dev.dtype, device=sorted_dev.device)
+        return [int(x) for x in torch.searchsorted(sorted_dev, v).cpu().tolist()]
+
     def voxel_downsample(self, pts, nrm, col, vs, cache):
         p, n, c = self.voxel_downsample_dev(pts, nrm, col, vs, cache)
         return p.cpu().numpy(), None if n is None else n.cpu().numpy(), None if c is None else c.cpu().numpy()

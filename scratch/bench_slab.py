@@ -80,10 +80,11 @@ for world in (1, 2, 4, 8):
             vc = {"xyz": raw}
             for r in range(world):
                 def layers(r=r):
-                    a = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r], vcuts[r + 1])[0]
-                    b = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r] - hl, vcuts[r])[0] if r > 0 else a[:0]
-                    c = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r + 1], vcuts[r + 1] + hl)[0] if r < world - 1 else a[:0]
-                    return eng.concat_rows([b, a, c])
+                    g = int(np.ceil(PD._bulk_halo(vh, vw, raw.shape[0], raw.shape[0] // 2, k) / 0.05))
+                    p, iz = eng.voxel_layers(raw, vc, 0.05, mn_, mx_, vcuts[r] - g if r > 0 else vcuts[r],
+                                             vcuts[r + 1] + g if r < world - 1 else vcuts[r + 1])
+                    a_, b_ = eng.sorted_positions(iz, (vcuts[r] - hl, vcuts[r + 1] + hl))
+                    return p[a_:b_]
                 layers()
                 vox_layers.append(timed(layers)[1])
     w = {"voxel_layers_rank_ms": vox_layers, "replicated_build_ms": build_ms, "replicated_search_ms_max": max(rep), "replicated_rank_ms": build_ms + max(rep),
