@@ -103,7 +103,7 @@ PcKnobs pc_read_knobs() {
         if (const char *e = getenv("PC_AMD_DENSE_FACTOR")) k.dense_factor = atof(e);
         k.no_postpone = on("PC_AMD_NO_POSTPONE");
         k.lazy_min = num("PC_AMD_LAZY_MIN", 1ll << 20);
-        k.ring_min = num("PC_AMD_RING_MIN", 4096);
+        k.ring_min = num("PC_AMD_RING_MIN", 65536);
         return k;
     }
 }

@@ -480,7 +480,9 @@ int pc_launch_batch_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArg
 
 // pc_knn_ring.hip: the open queries a ladder leaves, lane per query on the finest level with rings of several cells
 int pc_launch_ring_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
-                        uint32_t *answered, hipStream_t st);
+                        int64_t stride, uint32_t *answered, hipStream_t st);
+
+int pc_ring_eligible(pc_ctx *ctx, int dtype, const ScanArgs &A, const int32_t *list, int64_t count, uint32_t *out_dev, hipStream_t st);
 
 // pc_knn_wave.hip: one wave per listed query (A.qlist / A.qub / A.qcount).
 int pc_launch_wave_query(pc_ctx *ctx, const pc_grid *g, int mode, const ScanArgs &A, hipStream_t st);

@@ -31,7 +31,7 @@ constexpr int RING_FREE = 4;    // ... and when it has to find its bound on the 
 
 template <typename REC, int KS, int MODE>
 __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_ring_scan(ScanArgs A, const int32_t *__restrict__ list, uint32_t count,
-                                                        uint32_t *__restrict__ answered) {
+                                                        uint32_t stride, uint32_t *__restrict__ answered) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *park_k = reinterpret_cast<uint32_t *>(smem);           // [PARK_SLOTS][64]
     uint32_t *park_j = park_k + PARK_SLOTS * PC_WAVE;                // [PARK_SLOTS][64]
@@ -42,10 +42,11 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
     const GridParams &gp = A.gp;
     const REC *rec = reinterpret_cast<const REC *>(A.rec);
     const uint32_t qi = blockIdx.x * PC_WAVE + lane;
-    const bool active = qi < count;
+    bool active = qi < count;  // (the launch takes every stride-th entry of the list)
     double qx = 0.0, qy = 0.0, qz = 0.0;
     int32_t qid = 0;
-    if (active) RecTraits<REC>::load(rec + list[qi], qx, qy, qz, qid);
+    if (active) RecTraits<REC>::load(rec + list[(uint64_t)qi * stride], qx, qy, qz, qid);
+    if (active && A.qflag_out[qid] == 0) active = false;  // (answered by an earlier launch over a sample of the list)
     const double qv[3] = {qx, qy, qz};
     double u[3];
     int c[3];
@@ -378,44 +379,77 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
     });
 }
 
+// out[0] += listed queries whose bound fits the rings (the ball of the bound inside RING_MAX cells), out[1] += those that
+// come without a bound
+template <typename REC>
+__global__ __launch_bounds__(256) void k_ring_eligible(ScanArgs A, const int32_t *__restrict__ list, uint32_t count, uint32_t *__restrict__ out) {
+    const uint32_t qi = blockIdx.x * 256 + threadIdx.x;
+    bool fits = false, boundless = false;
+    if (qi < count) {
+        double x, y, z;
+        int32_t qid;
+        RecTraits<REC>::load(reinterpret_cast<const REC *>(A.rec) + list[qi], x, y, z, qid);
+        const float ub = A.qub_arr[qid];
+        boundless = !(ub < INFINITY);
+        fits = !boundless && sqrt((double)ub) * A.gp.s <= (double)RING_MAX;
+    }
+    const unsigned long long f = __ballot(fits), b = __ballot(boundless);
+    if ((threadIdx.x & 63) == 0) {
+        if (f) atomicAdd(out, (uint32_t)__popcll(f));
+        if (b) atomicAdd(out + 1, (uint32_t)__popcll(b));
+    }
+}
+
 template <typename REC, int KS>
-void launch_mode(int mode, unsigned nb, size_t lds, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count, uint32_t *answered) {
+void launch_mode(int mode, unsigned nb, size_t lds, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count, uint32_t stride, uint32_t *answered) {
     switch (mode) {
-        case M_KNN: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_KNN>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, answered); break;
-        case M_SOR: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_SOR>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, answered); break;
-        case M_NORMALS: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_NORMALS>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, answered); break;
-        case M_NNDIST: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_NNDIST>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, answered); break;
-        case M_ALL: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_ALL>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, answered); break;
+        case M_KNN: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_KNN>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, stride, answered); break;
+        case M_SOR: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_SOR>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, stride, answered); break;
+        case M_NORMALS: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_NORMALS>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, stride, answered); break;
+        case M_NNDIST: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_NNDIST>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, stride, answered); break;
+        case M_ALL: hipLaunchKernelGGL((k_ring_scan<REC, KS, M_ALL>), dim3(nb), dim3(PC_WAVE), lds, st, A, list, count, stride, answered); break;
         default: break;
     }
 }
 
 template <typename REC>
-void launch_ks(int ks, int mode, unsigned nb, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count, uint32_t *answered) {
+void launch_ks(int ks, int mode, unsigned nb, hipStream_t st, const ScanArgs &A, const int32_t *list, uint32_t count, uint32_t stride, uint32_t *answered) {
     const size_t lds = std::max((sizeof(double) + sizeof(uint32_t)) * PC_WAVE * (size_t)ks, 2 * sizeof(uint32_t) * PC_WAVE * (size_t)PARK_SLOTS);
     switch (ks) {
-        case 4: launch_mode<REC, 4>(mode, nb, lds, st, A, list, count, answered); break;
-        case 10: launch_mode<REC, 10>(mode, nb, lds, st, A, list, count, answered); break;
-        case 18: launch_mode<REC, 18>(mode, nb, lds, st, A, list, count, answered); break;
-        case 22: launch_mode<REC, 22>(mode, nb, lds, st, A, list, count, answered); break;
-        default: launch_mode<REC, 34>(mode, nb, lds, st, A, list, count, answered); break;
+        case 4: launch_mode<REC, 4>(mode, nb, lds, st, A, list, count, stride, answered); break;
+        case 10: launch_mode<REC, 10>(mode, nb, lds, st, A, list, count, stride, answered); break;
+        case 18: launch_mode<REC, 18>(mode, nb, lds, st, A, list, count, stride, answered); break;
+        case 22: launch_mode<REC, 22>(mode, nb, lds, st, A, list, count, stride, answered); break;
+        default: launch_mode<REC, 34>(mode, nb, lds, st, A, list, count, stride, answered); break;
     }
 }
 
 }  // namespace
 
-// One pass over the listed open queries (ascending sorted positions of the level A describes -- the finest;
-// A.qflag_out / A.qub_arr are the per-point flags and bounds).  answered: a device word that counts the
-// queries closed, or NULL.
+// One pass over `count` of the listed open queries, every stride-th entry of the list (ascending sorted positions of
+// the level A describes -- the finest; A.qflag_out / A.qub_arr are the per-point flags and bounds; entries whose flag
+// is clear already are left alone).  answered: a device word that counts the queries closed, or NULL.
 int pc_launch_ring_scan(pc_ctx *ctx, int dtype, int ks, int mode, const ScanArgs &A, const int32_t *list, int64_t count,
-                        uint32_t *answered, hipStream_t st) {
+                        int64_t stride, uint32_t *answered, hipStream_t st) {
     if (count <= 0) return PC_OK;
     if (ks > 34 || !A.qflag_out || !A.qub_arr) return pc_fail(ctx, PC_BAD_ARG, "ring scan");
     const unsigned nb = (unsigned)((count + PC_WAVE - 1) / PC_WAVE);
     if (dtype == PC_F32)
-        launch_ks<Rec32>(ks, mode, nb, st, A, list, (uint32_t)count, answered);
+        launch_ks<Rec32>(ks, mode, nb, st, A, list, (uint32_t)count, (uint32_t)stride, answered);
     else
-        launch_ks<Rec64>(ks, mode, nb, st, A, list, (uint32_t)count, answered);
+        launch_ks<Rec64>(ks, mode, nb, st, A, list, (uint32_t)count, (uint32_t)stride, answered);
+    PC_HIP(hipGetLastError());
+    return PC_OK;
+}
+
+// How many of the listed queries come with a bound that the rings hold (out_dev[0]) and how many without one (out_dev[1]).
+int pc_ring_eligible(pc_ctx *ctx, int dtype, const ScanArgs &A, const int32_t *list, int64_t count, uint32_t *out_dev, hipStream_t st) {
+    if (count <= 0) return PC_OK;
+    const unsigned nb = (unsigned)((count + 255) / 256);
+    if (dtype == PC_F32)
+        hipLaunchKernelGGL(k_ring_eligible<Rec32>, dim3(nb), dim3(256), 0, st, A, list, (uint32_t)count, out_dev);
+    else
+        hipLaunchKernelGGL(k_ring_eligible<Rec64>, dim3(nb), dim3(256), 0, st, A, list, (uint32_t)count, out_dev);
     PC_HIP(hipGetLastError());
     return PC_OK;
 }
