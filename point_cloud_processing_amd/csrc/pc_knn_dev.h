@@ -431,10 +431,28 @@ __device__ inline void emit_result(const ScanArgs &A, int64_t out_row, int cnt, 
             x[v] = y[v] = z[v] = 0.0;
             if (s0 + v < cnt) nb(s0 + v, d[v], x[v], y[v], z[v], id[v]);
         }
+        // rows of whole 16-byte groups leave as vector stores (a lane's row is its own: word by word every store
+        // instruction touches 64 cache lines for 4 bytes each)
+        static_assert(AT_ONCE == 4, "the vector stores below write four neighbours");
+        const bool vec = rows && (k & 3) == 0 && s0 + AT_ONCE <= k &&
+                         ((reinterpret_cast<uintptr_t>(A.out_idx) | reinterpret_cast<uintptr_t>(A.out_d2)) & 15) == 0;
+        if (vec) {
+            if (A.out_idx) *reinterpret_cast<int4 *>(A.out_idx + out_row * k + s0) = make_int4(id[0], id[1], id[2], id[3]);
+            if (A.out_d2) {
+                if (A.d2_f64) {
+                    double *o = reinterpret_cast<double *>(A.out_d2) + out_row * k + s0;
+                    *reinterpret_cast<double2 *>(o) = make_double2(d[0], d[1]);
+                    *reinterpret_cast<double2 *>(o + 2) = make_double2(d[2], d[3]);
+                } else {
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(A.out_d2) + out_row * k + s0) =
+                        make_float4((float)d[0], (float)d[1], (float)d[2], (float)d[3]);
+                }
+            }
+        }
 #pragma unroll
         for (int v = 0; v < AT_ONCE; v++) {
             const int s = s0 + v;
-            if (rows && s < k) {
+            if (rows && !vec && s < k) {
                 if (A.out_idx) A.out_idx[out_row * k + s] = id[v];
                 if (A.out_d2) {
                     if (A.d2_f64)

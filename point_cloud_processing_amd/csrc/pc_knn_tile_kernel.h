@@ -673,18 +673,25 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         const double r2eff = r2lim >= 0.0 ? r2lim : INFINITY;
         double dd[KS];
         uint32_t od[KS];
+        // (the long lists of a kernel that runs one wave per SIMD anyway keep the original indices they have just
+        // read with the records: rows and ties need no second look at global memory)
+        constexpr bool KEEP_ID = KS > 22 && KS <= 34 && (MODE == M_KNN || MODE == M_ALL);
+        int32_t ci[KEEP_ID ? KS : 1];
         int nsafe = 0, cnt = 0, nvalid = 0;
+        uint32_t last = 0;  // the largest listed key (the list's registers are free once this loop has read them)
 #pragma unroll
         for (int s = 0; s < KS; s++) {
+            last = L[s] != KEY_EMPTY ? L[s] : last;
             // (a key listed twice is the candidate a segment of odd length took along, met again in the walk)
             const bool valid = L[s] != KEY_EMPTY && (s == 0 || L[s] != L[s - 1]);
             od[s] = valid ? (L[s] & ORD_MASK) : 0u;
             double cx, cy, cz;
             int32_t cid;
             // (fp64 grids fetch the record by its sorted position: position 0 for a slot that is left out --
-            // candidate 0 of a block without candidates was never staged)
+            // candidate 0 of a block without candidates was never staged; fp32 candidates carry their original
+            // index in that word, read only where it is kept)
             TileRec<REC>::exact(rec, make_float4(cxyz[3 * od[s]], cxyz[3 * od[s] + 1], cxyz[3 * od[s] + 2],
-                                                 TileRec<REC>::kRelative && valid ? cws[od[s]] : 0.f), cx, cy, cz, cid);
+                                                 (TileRec<REC>::kRelative || KEEP_ID) && valid ? cws[od[s]] : 0.f), cx, cy, cz, cid);
             const double dx = qxd - cx, dy = qyd - cy, dz = qzd - cz;
             double d = dx * dx;
             d += dy * dy;
@@ -694,6 +701,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             nsafe += safe ? 1 : 0;
             cnt += in ? 1 : 0;
             dd[s] = in ? d : INFINITY;
+            if (KEEP_ID) ci[s] = cid;
         }
         const bool ok = nsafe >= k || bound == INFINITY || (r2lim >= 0.0 && bound >= r2lim);
         if (!ok) {
@@ -701,9 +709,6 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
             // what truncation (2^-12) and the fp32 measurement (the rounded frame of fp64 grids) can hide
             float ubf = INFINITY;
             if (nvalid >= k) {
-                uint32_t last = 0;
-#pragma unroll
-                for (int s = 0; s < KS; s++) last = L[s] != KEY_EMPTY ? L[s] : last;
                 const double th = (double)__uint_as_float(last & ~ORD_MASK) * (1.0 + 2.44140625e-4);
                 if (TileRec<REC>::kRelative) {
                     const double rt = sqrt(th) * (1.0 + 1e-6) + 4.76837158203125e-07 * bext;
@@ -752,6 +757,11 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 dd[s + 1] = fmax(da, db);
                 od[s] = gt ? ob : oa;
                 od[s + 1] = gt ? oa : ob;
+                if (KEEP_ID) {
+                    const int32_t ia = ci[s], ib = ci[s + 1];
+                    ci[s] = gt ? ib : ia;
+                    ci[s + 1] = gt ? ia : ib;
+                }
             }
         }
         // equal distances (rare): order those neighbours by original index
@@ -766,18 +776,29 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 for (int s = 0; s + 1 < KS; s++) {
                     const uint32_t oa = od[s], ob = od[s + 1];
                     bool gt = false;
-                    if (dd[s] == dd[s + 1] && dd[s] != INFINITY) gt = orig_index(oa) > orig_index(ob);
+                    if (dd[s] == dd[s + 1] && dd[s] != INFINITY) gt = KEEP_ID ? ci[s] > ci[s + 1] : orig_index(oa) > orig_index(ob);
                     od[s] = gt ? ob : oa;
                     od[s + 1] = gt ? oa : ob;
+                    if (KEEP_ID) {
+                        const int32_t ia = ci[s], ib = ci[s + 1];
+                        ci[s] = gt ? ib : ia;
+                        ci[s + 1] = gt ? ia : ib;
+                    }
                     swapped |= gt;
                 }
                 if (!__any(swapped)) break;
             }
         }
         cnt = min(cnt, k);
-        // Rows and mean distance straight from the sorted registers (no second look at the candidates);
-        // the long lists of k > 20 keep fewer registers alive by going through the generic consumer.
-        constexpr bool DIRECT = KS <= 22;
+#ifdef ABL_NOEMIT
+        if (dd[0] != 12345.0) { if (od[KS - 1] == 54321u) A.out_cnt[qid] = 1; continue; }
+#endif
+        // Rows and mean distance straight from the sorted registers (no second look at the candidates).  Lists up
+        // to 34 entries afford it: their kernels run one wave per SIMD whatever they keep alive, and the generic
+        // consumer's walk, four records in flight at a time with nothing else to run, cost 66 M voxels with k = 32
+        // 5 of a tile pass's 54 ms.  Longer lists go through the generic consumer.
+        constexpr bool DIRECT = KS <= 34;
+        auto index_at = [&](int s) { return KEEP_ID ? ci[KEEP_ID ? s : 0] : orig_index(od[s]); };
         const int64_t orow = out_row_of(A, qid, spos);  // row of the outputs
         if (DIRECT && (MODE == M_KNN || MODE == M_ALL) && (A.out_idx || A.out_d2 || A.out_cnt)) {
             const int64_t row = orow * k;
@@ -787,10 +808,10 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                     if (s < k) {
                         if (A.out_idx) {
                             int4 v;
-                            v.x = s < cnt ? orig_index(od[s]) : -1;
-                            v.y = s + 1 < cnt ? orig_index(od[s + 1]) : -1;
-                            v.z = s + 2 < cnt ? orig_index(od[s + 2]) : -1;
-                            v.w = s + 3 < cnt ? orig_index(od[s + 3]) : -1;
+                            v.x = s < cnt ? index_at(s) : -1;
+                            v.y = s + 1 < cnt ? index_at(s + 1) : -1;
+                            v.z = s + 2 < cnt ? index_at(s + 2) : -1;
+                            v.w = s + 3 < cnt ? index_at(s + 3) : -1;
                             *reinterpret_cast<int4 *>(A.out_idx + row + s) = v;
                         }
                         if (A.out_d2) {
@@ -812,7 +833,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 for (int s = 0; s < KS; s++) {
                     if (s < k) {  // wave-uniform
                         const bool have = s < cnt;
-                        if (A.out_idx) A.out_idx[row + s] = have ? orig_index(od[s]) : -1;
+                        if (A.out_idx) A.out_idx[row + s] = have ? index_at(s) : -1;
                         if (A.out_d2) {
                             const double d = have ? dd[s] : INFINITY;
                             if (A.d2_f64)
