@@ -150,8 +150,13 @@ __global__ __launch_bounds__(PC_WAVE) __attribute__((amdgpu_waves_per_eu(2))) vo
     while (__any(live)) {
         st_iter++;
         const bool need = live && pos >= tot;
-        if (__any(need && tighter)) drain();  // (rows are cut by the freshest bound)
-        if (need) {
+        // The look-up of new rows costs the wave three times a round of candidates whoever takes part: it waits until
+        // half of the walking lanes are out of candidates, or nobody has any left (66 M voxels, 2.3 M queries: 25.2 ->
+        // 19.8 ms; a quarter / 40 % / 60 % / two thirds / all of the lanes: 22.0 / 20.7 / 19.7 / 19.8 / 28.4 ms).
+        const int n_need = __popcll(__ballot(need)), n_live = __popcll(__ballot(live));
+        const bool pick = 2 * n_need >= n_live || !__any(live && pos < tot);
+        if (pick && __any(need && tighter)) drain();  // (rows are cut by the freshest bound)
+        if (pick && need) {
             pos = 0;
             tot = 0;
             if (idx == 0 && shell > 0) {

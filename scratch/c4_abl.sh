@@ -11,7 +11,9 @@ import csv, sys
 v = sys.argv[1]
 rows = list(csv.DictReader(open(f'gpurun_out/c4_abl_{v}/kt_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-t = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if "k_tile_scan" in r["Kernel_Name"]]
-print(v, "tile launches (ms):", ["%.2f" % x for x in t])
+import os
+kern = os.environ.get("C4_KERN", "k_tile_scan")
+t = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if kern in r["Kernel_Name"]]
+print(v, kern, "launches (ms):", ["%.2f" % x for x in t])
 PY
 done
