@@ -56,6 +56,22 @@ __global__ __launch_bounds__(256) void k_take(const uint32_t *__restrict__ src, 
     if (i < m) dst[i] = src[idx[i]];
 }
 
+// flags[tile of the key's cell] = 1 for every key (plain stores of the same value: no order matters)
+__global__ __launch_bounds__(256) void k_mark_tiles(const uint32_t *__restrict__ keys, int64_t n, int dx, int dy, int tx, int ty,
+                                                     int tz, int ntx, int nty, uint8_t *__restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t key = keys[i];
+    if (i > 0 && keys[i - 1] == key) return;  // (sorted keys: one store per occupied cell)
+    const uint32_t x = key % (uint32_t)dx;
+    key /= (uint32_t)dx;
+    const uint32_t y = key % (uint32_t)dy, z = key / (uint32_t)dy;
+    flags[((z / tz) * (uint32_t)nty + (y / ty)) * (uint32_t)ntx + (x / tx)] = 1;
+}
+
+// most tiles a grid may have for its occupied ones to be found by marking a byte per tile
+constexpr uint64_t MARK_TILES_MAX = 64ull << 20;
+
 // unique tile ids of the occupied cells, ascending (sparse grids only)
 // Linear ids of the tiles (of g's tile shape) that hold at least one of n sorted cell keys.
 int tile_list_from_keys(pc_ctx *ctx, const pc_grid *g, const uint32_t *keys, int64_t n, hipStream_t st, uint32_t **out,
@@ -63,6 +79,33 @@ int tile_list_from_keys(pc_ctx *ctx, const pc_grid *g, const uint32_t *keys, int
     *out = nullptr;
     *count = 0;
     const unsigned nb = (unsigned)((n + 255) / 256);
+    {
+        // Few enough tiles for a byte each: mark the occupied ones and compact the marks -- ascending tile ids without
+        // sorting anything (five launches and one read-back where the sort below takes some twenty and three; one LiDAR
+        // frame in fourteen has such a finest level, 60 k voxels in a few million tiles).
+        const uint64_t mx = (uint64_t)((g->gp.dim[0] + g->tile[0] - 1) / g->tile[0]), my = (uint64_t)((g->gp.dim[1] + g->tile[1] - 1) / g->tile[1]),
+                       mz = (uint64_t)((g->gp.dim[2] + g->tile[2] - 1) / g->tile[2]);
+        const uint64_t mt = mx * my * mz;
+        if (n > 0 && mt <= MARK_TILES_MAX) {
+            Scratch marks(ctx, (size_t)mt);
+            if (!marks.ok()) return pc_fail(ctx, PC_NOMEM, "tile marks");
+            uint32_t *list = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(std::min<int64_t>(n, (int64_t)mt), 1));
+            if (!list) return pc_fail(ctx, PC_NOMEM, "tile list");
+            PC_HIP(hipMemsetAsync(marks.p, 0, (size_t)mt, st));
+            hipLaunchKernelGGL(k_mark_tiles, dim3(nb), dim3(256), 0, st, keys, n, g->gp.dim[0], g->gp.dim[1], g->tile[0], g->tile[1],
+                               g->tile[2], (int)mx, (int)my, marks.as<uint8_t>());
+            PC_HIP(hipGetLastError());
+            int64_t nocc = 0;
+            const int rc = pc_compact_flags(ctx, marks.as<uint8_t>(), (int64_t)mt, reinterpret_cast<int32_t *>(list), &nocc, st);
+            if (rc != PC_OK) {
+                ctx->release(list);
+                return rc;
+            }
+            *out = list;
+            *count = nocc;
+            return PC_OK;
+        }
+    }
     Scratch flags(ctx, (size_t)n), heads(ctx, sizeof(int32_t) * (size_t)n);
     if (!flags.ok() || !heads.ok()) return pc_fail(ctx, PC_NOMEM, "tile list");
     hipLaunchKernelGGL(k_key_heads, dim3(nb), dim3(256), 0, st, keys, n, flags.as<uint8_t>());
