@@ -254,6 +254,7 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
                 RecTraits<REC>::load(qsrc + sp, x, y, z, id);
                 any = any || flag_live(A.qflag_in[id], A.flag_max);
             }
+            if (__any(any)) break;  // (one is enough: the batches below look at their own flags)
         }
         if (!__any(any)) return 0;
     }
