@@ -44,6 +44,7 @@ struct PcKnobs {
     bool no_postpone = false;      // PC_AMD_NO_POSTPONE: sparse tiles' queries are not postponed tile by tile before the first list pass (A/B switch)
     double dense_factor = 16.0;    // PC_AMD_DENSE_FACTOR: a grid keeps a table of cell offsets while it has at most this many cells per point
     bool no_probe = false;         // PC_AMD_NO_PROBE: every cell edge tried is sorted, not counted first (A/B switch)
+    bool no_mark_tiles = false;    // PC_AMD_NO_MARK_TILES: the occupied tiles of a sparse grid are always found by sorting tile ids (A/B switch)
     bool no_ring = false;          // PC_AMD_NO_RING: no lane-per-query ring pass before the wave-per-query kernel (A/B switch)
     int64_t ring_min = 65536;      // PC_AMD_RING_MIN: open queries from which that pass is worth its list
     bool no_bucket_build = false;  // PC_AMD_NO_BUCKET_BUILD: always the general index build (A/B switch)

@@ -100,6 +100,7 @@ PcKnobs pc_read_knobs() {
         k.no_ring = on("PC_AMD_NO_RING");
         k.thin_tile = (int)num("PC_AMD_THIN_TILE", 0);
         k.no_probe = on("PC_AMD_NO_PROBE");
+        k.no_mark_tiles = on("PC_AMD_NO_MARK_TILES");
         if (const char *e = getenv("PC_AMD_DENSE_FACTOR")) k.dense_factor = atof(e);
         k.no_postpone = on("PC_AMD_NO_POSTPONE");
         k.lazy_min = num("PC_AMD_LAZY_MIN", 1ll << 20);

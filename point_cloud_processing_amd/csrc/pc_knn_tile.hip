@@ -86,7 +86,7 @@ int tile_list_from_keys(pc_ctx *ctx, const pc_grid *g, const uint32_t *keys, int
         const uint64_t mx = (uint64_t)((g->gp.dim[0] + g->tile[0] - 1) / g->tile[0]), my = (uint64_t)((g->gp.dim[1] + g->tile[1] - 1) / g->tile[1]),
                        mz = (uint64_t)((g->gp.dim[2] + g->tile[2] - 1) / g->tile[2]);
         const uint64_t mt = mx * my * mz;
-        if (n > 0 && mt <= MARK_TILES_MAX) {
+        if (n > 0 && mt <= MARK_TILES_MAX && !ctx->knobs.no_mark_tiles) {
             Scratch marks(ctx, (size_t)mt);
             if (!marks.ok()) return pc_fail(ctx, PC_NOMEM, "tile marks");
             uint32_t *list = (uint32_t *)ctx->alloc(sizeof(uint32_t) * (size_t)std::max<int64_t>(std::min<int64_t>(n, (int64_t)mt), 1));

@@ -100,6 +100,30 @@ def test_level_passes_agree(hip, oracle, monkeypatch, k):
     assert np.array_equal(a_self[0], ridx) and np.array_equal(a_self[1], rd2)
 
 
+@pytest.mark.parametrize("apart", [0.1, 1.0])
+def test_tile_list_of_a_sparse_grid_by_marks_and_by_sort(hip, oracle, monkeypatch, apart):
+    """Two small clusters a long way apart: the finest level has far more cells than points (sparse index), so the
+    tile kernel works from a list of occupied tiles -- for the cloud's own points and, per search, for the tiles
+    that hold external queries.  The list made by marking a byte per tile and the one made by sorting tile ids give
+    the same answers, which are the oracle's.  (0.1: a few hundred thousand tiles, marked unless switched off; 1.0: hundreds of
+    millions, sorted either way.)"""
+    rng = np.random.default_rng(31)
+    a = rng.normal(0.0, 0.05, (30_000, 3))
+    b = rng.normal(0.0, 0.05, (30_000, 3)) + apart * np.array([40.0, 25.0, 10.0])
+    p = np.concatenate([a, b]).astype(np.float32).astype(np.float64)
+    q = (p[rng.permutation(len(p))[:20_000]] + rng.normal(0, 0.01, (20_000, 3))).astype(np.float32).astype(np.float64)
+    a_self, a_ext = hip.knn(p, None, 8, -1.0, {}), hip.knn(p, q, 8, -1.0, {})
+    monkeypatch.setenv("PC_AMD_NO_MARK_TILES", "1")
+    other = _engine_of_this_environment()
+    b_self, b_ext = other.knn(p, None, 8, -1.0, {}), other.knn(p, q, 8, -1.0, {})
+    assert all(np.array_equal(x, y) for x, y in zip(a_self, b_self))
+    assert all(np.array_equal(x, y) for x, y in zip(a_ext, b_ext))
+    ridx, rd2, rcnt = oracle.knn(p, q, 8)
+    assert np.array_equal(a_ext[0], ridx) and np.array_equal(a_ext[1], rd2) and np.array_equal(a_ext[2], rcnt)
+    ridx, rd2, rcnt = oracle.Grid(p).knn_self(8)
+    assert np.array_equal(a_self[0], ridx) and np.array_equal(a_self[1], rd2)
+
+
 def test_crowded_patch_gets_finer_levels(hip, oracle):
     """A small patch far denser than the rest (more candidates around its points than a tile stages, at
     every level of the index): answered through the finer grids made on demand and the wave-per-query
