@@ -230,8 +230,10 @@ int pc_grid_coarser(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid
 // level `level` of a multi-level index (cells 2^level times the finest's), made from the records of `last`, the coarsest
 // level there is, and hung behind it: levels in between are left out; *out = NULL where there is none to make
 int pc_grid_level(pc_ctx *ctx, const pc_grid *last, int level, hipStream_t st, const pc_grid **out);
+// (qrows_out, if given: the row directory of the sorted query keys -- first sorted position of every (y, z) row of g's cells,
+// dim[1] * dim[2] + 2 entries -- so that a look-up among the queries stays inside one row)
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
-                   hipStream_t st);
+                   uint32_t *qrows_out, hipStream_t st);
 
 // pc_knn_tile.hip
 // The tile of the cooperative kNN kernel for a cloud that fills its box with `occ` points per cell on a grid of `dim`

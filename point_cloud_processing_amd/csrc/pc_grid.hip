@@ -1356,7 +1356,7 @@ int pc_grid_finer(pc_ctx *ctx, const pc_grid *g, hipStream_t st, const pc_grid *
 // External queries binned into a grid: records {x, y, z, query row} in the order of the grid's cell
 // keys (ties by query row) and the sorted keys themselves.  The queries have the grid's dtype.
 int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq, void *qrec_out, uint32_t *qkeys_out,
-                   hipStream_t st) {
+                   uint32_t *qrows_out, hipStream_t st) {
     const size_t nb = sizeof(uint32_t) * (size_t)std::max<int64_t>(nq, 1);
     Scratch keys(ctx, nb), keys2(ctx, nb), vals(ctx, nb), vals2(ctx, nb);
     if (!keys.ok() || !keys2.ok() || !vals.ok() || !vals2.ok()) return pc_fail(ctx, PC_NOMEM, "query binning scratch");
@@ -1380,6 +1380,13 @@ int pc_bin_queries(pc_ctx *ctx, const pc_grid *g, const void *q_dev, int64_t nq,
                            (const double *)q_dev, sv, nq, (Rec64 *)qrec_out, (int32_t *)nullptr);
     PC_HIP(hipGetLastError());
     PC_HIP(hipMemcpyAsync(qkeys_out, sk, sizeof(uint32_t) * (size_t)nq, hipMemcpyDeviceToDevice, st));
+    if (qrows_out) {
+        const int64_t nrows = (int64_t)g->gp.dim[1] * g->gp.dim[2];
+        PC_HIP(hipMemsetAsync(qrows_out, 0, sizeof(uint32_t) * (size_t)(nrows + 2), st));
+        hipLaunchKernelGGL(k_row_runs, dim3(blocks_for(nq, 256)), dim3(256), 0, st, sk, nq, (uint32_t)g->gp.dim[0], qrows_out);
+        PC_HIP(hipGetLastError());
+        PC_TRY(pc_exclusive_scan_u32(ctx, qrows_out, nrows + 2, st));
+    }
     return PC_OK;
 }
 

@@ -502,12 +502,20 @@ int pc_knn(pc_ctx *ctx, const pc_grid *grid, const void *queries_dev, int qdtype
         // many queries of the grid's own type: bin them into the grid (cell key, radix sort, records)
         // and let the tile kernel answer them like the grid's own points
         const size_t rb = grid->dtype == PC_F32 ? sizeof(Rec32) : sizeof(Rec64);
-        Scratch qrec(ctx, rb * (size_t)nq), qkeys(ctx, sizeof(uint32_t) * (size_t)nq);
-        if (!qrec.ok() || !qkeys.ok()) return pc_fail(ctx, PC_NOMEM, "query records");
-        PC_TRY(pc_bin_queries(ctx, grid, queries_dev, nq, qrec.p, qkeys.as<uint32_t>(), (hipStream_t)stream));
+        // (The tile kernel finds the queries of a tile's rows of cells among the sorted query keys: with a directory of
+        // the rows a search runs over the few dozen queries of one row instead of all of them -- some twenty dependent
+        // loads less per tile; 2 M queries against 2 M points, k = 1: tile pass 610 -> 518 us.)
+        const int64_t qnrows = (int64_t)grid->gp.dim[1] * grid->gp.dim[2];
+        const bool with_rows = qnrows + 2 <= 16 * nq + 65536;
+        Scratch qrec(ctx, rb * (size_t)nq), qkeys(ctx, sizeof(uint32_t) * (size_t)nq),
+            qrows(ctx, with_rows ? sizeof(uint32_t) * (size_t)(qnrows + 2) : 0);
+        if (!qrec.ok() || !qkeys.ok() || !qrows.ok()) return pc_fail(ctx, PC_NOMEM, "query records");
+        PC_TRY(pc_bin_queries(ctx, grid, queries_dev, nq, qrec.p, qkeys.as<uint32_t>(), with_rows ? qrows.as<uint32_t>() : nullptr,
+                              (hipStream_t)stream));
         A.qrec = qrec.p;
         A.qraw = queries_dev;
-        A.qci = CellIndex{nullptr, qkeys.as<uint32_t>(), (uint32_t)nq, nullptr, 0u};
+        A.qci = CellIndex{nullptr, qkeys.as<uint32_t>(), (uint32_t)nq, with_rows ? qrows.as<uint32_t>() : nullptr,
+                          (uint32_t)grid->gp.dim[0]};
         return launch_scan<M_KNN>(ctx, grid, qdtype, A, (hipStream_t)stream);
     }
     A.queries = queries_dev;

@@ -638,7 +638,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
     for (int i = 0; i < nlv; i++) {
         const pc_grid *l = lv[i];
         if (A.qrec && i > 0) {
-            if (binned_level != i) PC_TRY(pc_bin_queries(ctx, l, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+            if (binned_level != i) PC_TRY(pc_bin_queries(ctx, l, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), nullptr, st));
             binned_level = i;
             A.qrec = qrec_l.p;
             A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq, nullptr, 0u};
@@ -934,7 +934,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             if (batch_passes && ks <= batch_max_ks && i + 1 < nlv) {
                 const pc_grid *nl = lv[i + 1];
                 if (qrec0) {
-                    PC_TRY(pc_bin_queries(ctx, nl, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+                    PC_TRY(pc_bin_queries(ctx, nl, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), nullptr, st));
                     binned_level = i + 1;
                 }
                 PC_TRY(pc_batch_open_list(ctx, g->dtype, qrec0 ? qrec_l.p : nl->rec, qrec0 ? A.nq : nl->n, qflag,
@@ -975,7 +975,7 @@ int pc_launch_tile_scan(pc_ctx *ctx, const pc_grid *g, int mode, ScanArgs &A, hi
             if (!nf) break;
             fine = nf;
             if (qrec0) {
-                PC_TRY(pc_bin_queries(ctx, fine, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), st));
+                PC_TRY(pc_bin_queries(ctx, fine, A.qraw, A.nq, qrec_l.p, qkeys_l.as<uint32_t>(), nullptr, st));
                 A.qrec = qrec_l.p;
                 A.qci = CellIndex{nullptr, qkeys_l.as<uint32_t>(), (uint32_t)A.nq, nullptr, 0u};
             }

@@ -201,11 +201,24 @@ __device__ __forceinline__ int tile_body(const ScanArgs &A, char *smem, const in
         const int y = lo[1] + lane - rz0 * nry, z = lo[2] + rz0;
         const int64_t row = (int64_t)(((uint32_t)z * (uint32_t)gp.dim[1] + (uint32_t)y) * (uint32_t)gp.dim[0]);  // < 2^32 cells
         my_row_key = (uint32_t)row;
-        row_begin = cell_begin(A.ci, row + lo[0]);
-        row_cnt = cell_begin(A.ci, row + hi[0] + 1) - row_begin;
+        // (a searched index looks both ends of a range up together, several pivots per round trip)
+        if (A.ci.table) {
+            row_begin = cell_begin(A.ci, row + lo[0]);
+            row_cnt = cell_begin(A.ci, row + hi[0] + 1) - row_begin;
+        } else {
+            uint32_t e;
+            cell_range(A.ci, row + lo[0], row + hi[0] + 1, row_begin, e);
+            row_cnt = e - row_begin;
+        }
         if (y >= c0[1] && y <= c1[1] && z >= c0[2] && z <= c1[2]) {  // a row of the tile itself
-            q_begin = cell_begin(qix, row + c0[0]);
-            q_cnt = cell_begin(qix, row + c1[0] + 1) - q_begin;
+            if (qix.table) {
+                q_begin = cell_begin(qix, row + c0[0]);
+                q_cnt = cell_begin(qix, row + c1[0] + 1) - q_begin;
+            } else {
+                uint32_t e;
+                cell_range(qix, row + c0[0], row + c1[0] + 1, q_begin, e);
+                q_cnt = e - q_begin;
+            }
             if (!A.qflag_in && !A.qrec) {  // first pass: restrict to the caller's sorted-position range
                 const int64_t b = max((int64_t)q_begin, A.s_begin), e = min((int64_t)q_begin + q_cnt, A.s_end);
                 q_begin = (uint32_t)b;
