@@ -473,7 +473,7 @@ def bench_c4(h):
                                      f"query-shard x{h.world}, replicated voxel pass and index")})
     r["steps"], r["warmup"] = reps, 1
     r["step_parts_ms"] = parts
-    r["roofline"] = {"bound": "hbm", "kernel": "k_tile_scan / k_batch_scan<Rec64,34,M_ALL> over 8 index levels (uneven cloud)",
+    r["roofline"] = {"bound": "hbm", "kernel": "k_tile_scan / k_batch_scan<Rec64,34,M_ALL> and k_ring_scan over the index levels the search makes (uneven cloud)",
                      "achieved": alg_knn / (search_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_knn / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "traffic_source": "not collected", "algorithmic_bytes_per_launch": alg_knn,
