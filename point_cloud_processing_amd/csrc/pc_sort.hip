@@ -223,6 +223,8 @@ __global__ __launch_bounds__(CMP_THREADS) void k_compact_count(const uint8_t *__
     uint32_t tot;
     block_exclusive_scan(s, &tot, lds);
     if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+    // (the entry behind the block counts becomes the total in the scan that follows: it starts at zero)
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[gridDim.x] = 0u;
 }
 
 __global__ __launch_bounds__(CMP_THREADS) void k_compact_write(const uint8_t *__restrict__ flags, int64_t n,
@@ -312,8 +314,7 @@ int pc_compact_flags(pc_ctx *ctx, const uint8_t *flags, int64_t n, int32_t *out_
     Scratch counts(ctx, sizeof(uint32_t) * (size_t)(nb + 1));
     if (!counts.ok()) return pc_fail(ctx, PC_NOMEM, "compaction scratch");
     uint32_t *c = counts.as<uint32_t>();
-    PC_HIP(hipMemsetAsync(c + nb, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c);
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c);  // (also zeroes c[nb])
     PC_TRY(pc_exclusive_scan_u32(ctx, c, nb + 1, st));  // c[nb] becomes the total
     if (out_idx) hipLaunchKernelGGL(k_compact_write, dim3((unsigned)nb), dim3(CMP_THREADS), 0, st, flags, n, c, out_idx);
     PC_HIP(hipGetLastError());
