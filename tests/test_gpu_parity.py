@@ -241,6 +241,20 @@ def test_bbox_affine(hip, oracle):
     assert np.array_equal(got, out)
 
 
+@pytest.mark.parametrize("n", [65_536, 300_001, 1_000_003])
+def test_bbox_of_large_fp32_clouds(hip, n):
+    """Bounding boxes of large fp32 clouds (grid-stride kernel, 1024 blocks): extremes anywhere -- first point, last
+    point, in the middle -- come out exactly."""
+    rng = np.random.default_rng(n)
+    p = (rng.random((n, 3)) * np.array([3.0, 70.0, 0.5]) + np.array([-1.0, 5.0, 100.0])).astype(np.float32)
+    p[0] = [-9.0, 4.0, 99.0]
+    p[n - 1] = [9.0, 4.5, 101.5]
+    p[n - 2, 1] = 200.0
+    p[n // 2, 2] = -3.0
+    mn, mx = hip.bbox(p, {})
+    assert np.array_equal(mn, p.min(0).astype(np.float64)) and np.array_equal(mx, p.max(0).astype(np.float64))
+
+
 def test_determinism(hip):
     p = D.uniform_cube(30000, 97)
     a = hip.knn(p, None, 16, -1.0, {})
